@@ -1,0 +1,258 @@
+"""CPU suite: pin the oracle against (a) outputs of the reference's own functions
+(tests/golden/ref_*.npz, made by tests/golden/make_golden.py in the build container) and
+(b) the known-answer tests SURVEY.md 8(c) derives from the reference formulas."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---------------------------------------------------------------- reference-run fixtures
+@pytest.mark.parametrize("case", ["small", "rect", "lego64"])
+def test_get_rays_matches_reference(golden_dir, case):
+    g = _load(golden_dir, "ref_get_rays.npz")
+    H, W = g[f"{case}_HW"]
+    o, d = O.get_rays(int(H), int(W), g[f"{case}_K"], g[f"{case}_c2w"], dtype=torch.float64)
+    # reference computes in numpy with a float64 K and float32 c2w -> float64 results
+    np.testing.assert_allclose(d.numpy(), g[f"{case}_d"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(o.numpy(), g[f"{case}_o"], rtol=0, atol=0)
+
+
+def test_get_rays_lego800_subset(golden_dir):
+    g = _load(golden_dir, "ref_get_rays.npz")
+    H, W = g["lego800_HW"]
+    o, d = O.get_rays(int(H), int(W), g["lego800_K"], g["lego800_c2w"], dtype=torch.float64)
+    idx = torch.from_numpy(g["lego800_idx"])
+    np.testing.assert_allclose(d.reshape(-1, 3)[idx].numpy(), g["lego800_d"], rtol=0, atol=1e-12)
+    rc = O.select_coords(idx, int(W))
+    assert torch.equal(rc[:, 0] * int(W) + rc[:, 1], idx)
+    # KAT 9: centre pixel looks down -z of the camera, origin = translation everywhere
+    c = (int(H) // 2) * int(W) + int(W) // 2
+    np.testing.assert_allclose(d.reshape(-1, 3)[c].numpy(), -g["lego800_c2w"][:3, 2].astype(np.float64), atol=1e-12)
+    assert torch.equal(o.reshape(-1, 3)[0].float(), torch.from_numpy(g["lego800_c2w"][:3, 3]))
+
+
+@pytest.mark.parametrize("tag", ["const", "zero", "peaky", "spike", "jitter", "small", "signed"])
+def test_inverse_cdf_matches_reference_bitwise(golden_dir, tag):
+    g = _load(golden_dir, "ref_inverse_cdf.npz")
+    z, w, u = (torch.from_numpy(g[f"{tag}_{k}"]) for k in "zwu")
+    out, cdf, inds, below, above = O.inverse_cdf_parts(z, w, u)
+    # same torch build, same op sequence -> bit-identical
+    assert torch.equal(out, torch.from_numpy(g[f"{tag}_out"]))
+    assert inds.dtype == torch.int64 and int(inds.max()) <= z.shape[-1] + 1
+    if tag in ("const", "zero"):   # KAT 8: uniform pdf -> linear cdf -> z_new in [zmid_min, zmid_max]
+        zm = 0.5 * (z[..., 1:] + z[..., :-1])
+        assert float(out.min()) >= float(zm.min()) - 1e-6 and float(out.max()) <= float(zm.max()) + 1e-6
+
+
+def test_inverse_cdf_range_lego(golden_dir):
+    g = _load(golden_dir, "ref_inverse_cdf.npz")
+    out = g["peaky_out"]
+    assert out.shape == (8, 128) and not np.isnan(out).any()
+    assert out.min() >= 2.0317 - 1e-3 and out.max() <= 5.9683 + 1e-3
+
+
+def test_config_parser_defaults_match_reference(golden_dir):
+    from nerf_meets_mlx_amd import config_parser as C
+    with open(os.path.join(golden_dir, "ref_config_defaults.json")) as fp:
+        ref = json.load(fp)
+    mine = vars(C.config_parser().parse_args(args=[]))
+    assert mine == ref
+    with open(os.path.join(golden_dir, "ref_config_lego.json")) as fp:
+        lego = json.load(fp)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as fp:
+        fp.write("\n".join(f"{k} = {v}" for k, v in lego["file"].items()) + "\n\n")
+        path = fp.name
+    cfg = C.load_config(None, path)
+    os.remove(path)
+    assert cfg == lego["loaded"]
+    args = C.update_NeRF_args(C.config_parser().parse_args(args=[]), cfg, ref_quirks=True)
+    assert vars(args) == lego["args"]
+    args = C.update_NeRF_args(C.config_parser().parse_args(args=[]), cfg, ref_quirks=False)
+    assert args.use_viewdirs is True and args.white_bkgd is True and args.half_res is True
+
+
+# ---------------------------------------------------------------- known-answer tests
+def test_kat_pose_spherical():
+    m = O.pose_spherical(-180.0, -30.0, 4.0).numpy()
+    want = np.array([[1, 0, 0, 0], [0, .5, -.8660254, -3.4641016], [0, .8660254, .5, 2], [0, 0, 0, 1]], np.float32)
+    np.testing.assert_allclose(m, want, atol=2e-6)
+    m0 = O.pose_spherical(0.0, -30.0, 4.0).numpy()
+    np.testing.assert_allclose(np.linalg.norm(m0[:3, 3]), 4.0, atol=1e-5)
+    np.testing.assert_allclose(m0[:3, :3] @ m0[:3, :3].T, np.eye(3), atol=1e-6)
+
+
+def test_kat_focal():
+    assert abs(0.5 * 800 / math.tan(0.5 * 0.6911112070083618) - 1111.1110312) < 1e-4
+    assert abs(0.5 * 400 / math.tan(0.5 * 0.6911112070083618) - 555.5555156) < 1e-4
+
+
+def test_kat_embedder_frequencies_and_layout():
+    assert O.embedder_freqs(10).tolist() == [0, 1, 4, 9, 16, 25, 36, 49, 64, 81]
+    assert O.embedder_freqs(4).tolist() == [0, 1, 4, 9]
+    assert O.embedder_freqs(4, ref_quirks=False).tolist() == [1, 2, 4, 8]
+    x = torch.randn(5, 3)
+    e = O.embedder(x, 10)
+    assert e.shape == (5, 63)
+    assert torch.equal(e[:, :3], x)
+    assert torch.all(e[:, 3:6] == 0) and torch.all(e[:, 6:9] == 1)     # band 0 -> sin 0, cos 0
+    np.testing.assert_allclose(e[:, 9:12], torch.sin(x), atol=0)
+    np.testing.assert_allclose(e[:, 12:15], torch.cos(x), atol=0)
+    assert O.embedder(x, 4).shape == (5, 27)
+    pos = torch.randn(2, 4, 3); d = torch.randn(2, 3)
+    emb = O.embed(pos, d)
+    assert emb.shape == (8, 90)
+    assert torch.equal(emb[0:4, 63:], emb[0:1, 63:].expand(4, 27))       # dir repeated to every sample
+
+
+def test_kat_sinusoidal_encoding():
+    x = torch.tensor([[3.0, 7.0], [0.0, 399.0]])
+    e = O.sinusoidal_encoding(x, 10, 0.0, 8.0, False)
+    assert e.shape == (2, 40)
+    fr = 2.0 ** torch.linspace(0.0, 8.0, 10)
+    np.testing.assert_allclose(fr[[0, 1, 2, -1]].numpy(), [1, 1.8517494, 3.4289756, 256], rtol=1e-6)
+    np.testing.assert_allclose(e[0, :10], torch.sin(3.0 * fr), atol=1e-6)        # dim-major, freq-minor
+    np.testing.assert_allclose(e[0, 10:20], torch.sin(7.0 * fr), atol=1e-6)
+    np.testing.assert_allclose(e[0, 20:30], torch.sin(3.0 * fr + math.pi / 2), atol=1e-6)
+    e2 = O.sinusoidal_encoding(x, 10, 0.0, 8.0, True)
+    assert e2.shape == (2, 42) and torch.equal(e2[:, -2:], x)                    # raw input at the END
+    # `max_exp if max_exp else n-1` (sinusoidal.py:28): 0.0 is falsy -> replaced
+    e3 = O.sinusoidal_encoding(x, 4, None, None, False)
+    np.testing.assert_allclose(e3[0, :4], torch.sin(3.0 * torch.tensor([1., 2., 4., 8.])), atol=1e-6)
+
+
+def test_kat_param_counts_and_shapes():
+    a = O.NerfArch()
+    assert a.n_params() == 595844
+    shapes = {n: (o, i) for n, o, i in a.layer_shapes()}
+    assert shapes["pos0"] == (256, 63) and shapes["pos5"] == (256, 319) and shapes["dir0"] == (128, 283)
+    assert shapes["alpha"] == (1, 256) and shapes["rgb"] == (3, 128)
+    macs = sum(o * i for _, o, i in a.layer_shapes())
+    assert macs == 593408
+    img = O.NerfArch(channel_input=40, channel_input_views=0, channel_output=3, use_viewdirs=False)
+    assert img.n_params() == 482051 and sum(o * i for _, o, i in img.layer_shapes()) == 480000
+    p = O.init_params(a, 0)
+    flat = O.flatten_params(a, p)
+    assert flat.numel() == 595844
+    p2 = O.unflatten_params(a, flat)
+    assert all(torch.equal(p[k][0], p2[k][0]) and torch.equal(p[k][1], p2[k][1]) for k in p)
+    out = O.nerf_forward(a, p, torch.randn(7, 90))
+    assert out.shape == (7, 4)
+
+
+def test_kat_uniform_sample_z():
+    z = O.sample_z_uniform(torch.full((3, 1), 2.0), torch.full((3, 1), 6.0), 64)
+    want = 2.0 + 4.0 * torch.arange(64, dtype=torch.float64) / 63
+    np.testing.assert_allclose(z[1].double().numpy(), want.numpy(), atol=5e-7)
+    zl = O.sample_z_lindisp(torch.full((1, 1), 2.0), torch.full((1, 1), 6.0), 8)
+    assert float(zl[0, 0]) == 0.0 and float(zl[0, -1]) == 0.0                    # Q12 literal
+    zz = O.add_noise_z(z, 0.0, None)
+    assert zz is z
+    t = torch.rand(3, 64)
+    zj = O.add_noise_z(z, 1.0, t)
+    mids = 0.5 * (z[:, 1:] + z[:, :-1])
+    assert torch.all(zj[:, 1:-1] >= mids[:, :-1] - 1e-6) and torch.all(zj[:, 1:-1] <= mids[:, 1:] + 1e-6)
+    assert torch.all(zj[:, 0] >= 2.0) and torch.all(zj[:, -1] <= 6.0)
+
+
+def test_kat_raw2outputs_closed_forms():
+    B, n, sig = 4, 64, 1.7
+    z = torch.linspace(2.0, 6.0, n, dtype=torch.float64).expand(B, n)
+    d = torch.tensor([[0.0, 0.0, -1.0]], dtype=torch.float64).expand(B, 3)     # unit |d|
+    raw = torch.zeros(B, n, 4, dtype=torch.float64)
+    raw[..., :3] = torch.tensor([0.2, 0.5, 0.9], dtype=torch.float64)
+    raw[..., 3] = sig
+    rgb, disp, acc, w, depth = O.raw2outputs(raw, z, d, 0.0, False)
+    D = 4.0 / 63
+    k = torch.arange(n, dtype=torch.float64)
+    Tk = torch.exp(-sig * D * k)
+    want = (1 - math.exp(-sig * D)) * Tk
+    want[-1] = Tk[-1]
+    np.testing.assert_allclose(w[0, :, 0].numpy(), want.numpy(), rtol=1e-10)
+    np.testing.assert_allclose(acc.numpy(), 1.0, rtol=1e-12)
+    assert w.shape == (B, n, 1) and rgb.shape == (B, 3) and disp.shape == (B, 1) and depth.shape == (B, 1)
+    np.testing.assert_allclose(rgb[0].numpy(), [0.2, 0.5, 0.9], rtol=1e-10)
+    # sigma == 0: all weights 0; white bkgd -> rgb == 1; disp = NaN (0/0) (Q11)
+    raw[..., 3] = 0.0
+    rgb, disp, acc, w, depth = O.raw2outputs(raw, z, d, 0.0, True)
+    assert torch.all(w == 0) and torch.all(rgb == 1.0) and torch.isnan(disp).all()
+    # sigma < 0: alpha = 0 but T grows above 1 (Q10): weights stay 0, no NaN
+    raw[..., 3] = -0.5
+    raw[:, 10, 3] = 2.0
+    rgb, disp, acc, w, depth = O.raw2outputs(raw, z, d, 0.0, False)
+    T10 = math.exp(0.5 * D * 10)
+    np.testing.assert_allclose(w[0, 10, 0].item(), (1 - math.exp(-2.0 * D)) * T10, rtol=1e-10)
+    assert T10 > 1.0 and float(w[0, :10].abs().sum()) == 0.0
+    # |d| scaling
+    rgb2, *_ = O.raw2outputs(raw, z, 2 * d, 0.0, False)
+    assert not torch.allclose(rgb2, rgb)
+
+
+def test_kat_sh_axis_aligned():
+    d = torch.tensor([[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]], dtype=torch.float64)
+    e = O.sh_encoding(d, 4)
+    assert e.shape == (3, 25)
+    np.testing.assert_allclose(e[:, 0].numpy(), 0.28209479177387814)
+    np.testing.assert_allclose(e[0, 1:4].numpy(), [0, 0.4886025119029199, 0])
+    np.testing.assert_allclose(e[1, 1:4].numpy(), [0, 0, 0.4886025119029199])
+    np.testing.assert_allclose(e[0, 6].item(), 0.9461746957575601 - 0.31539156525251999)
+    np.testing.assert_allclose(e[0, 20].item(), 0.10578554691520431 * 8)
+    for deg, nout in [(0, 1), (1, 4), (2, 9), (3, 16)]:
+        assert O.sh_encoding(d, deg).shape == (3, nout)
+        assert torch.equal(O.sh_encoding(d, deg), e[:, :nout])
+
+
+def test_kat_hash():
+    T = 2 ** 19
+    c = torch.tensor([[1, 0, 0], [0, 1, 0], [0, 0, 1], [3, 5, 7], [2047, 2048, 1]])
+    h = O.hash_coords(c, T).tolist()
+    def ref(x, y, z):
+        return ((x * 1) ^ ((y * 2654435761) % 2 ** 32) ^ ((z * 805459861) % 2 ** 32)) % T
+    assert h == [ref(*row) for row in c.tolist()]
+    assert h[0] == 1 and h[1] == 2654435761 % T and h[2] == 805459861 % T
+    res = O.hashgrid_resolutions(16, 16, 2048)
+    assert res == [16, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482, 2048]
+    # trilinear: at an integer lattice point floor == ceil -> offset 0 -> weight all on the floor corner
+    tables = torch.randn(2, 64, 2, dtype=torch.float64)
+    x = torch.tensor([[0.25, 0.5, 0.75]], dtype=torch.float64)
+    e = O.hashgrid_encoding(x, tables, [4, 8])
+    idx0 = O.hash_coords(torch.tensor([[1, 2, 3]]), 64)
+    np.testing.assert_allclose(e[0, :2].numpy(), tables[0][idx0][0].numpy())
+    assert e.shape == (1, 4)
+
+
+def test_kat_adam_and_lr():
+    p = torch.tensor([1.0, -2.0]); g = torch.tensor([0.5, -0.25])
+    m = torch.zeros(2); v = torch.zeros(2)
+    O.adam_step(p, g, m, v, lr=0.1)
+    np.testing.assert_allclose(m.numpy(), 0.1 * g.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(v.numpy(), 0.001 * (g ** 2).numpy(), rtol=1e-5)
+    want = torch.tensor([1.0, -2.0]) - 0.1 * (0.1 * g) / (torch.sqrt(0.001 * g * g) + 1e-8)
+    np.testing.assert_allclose(p.numpy(), want.numpy(), rtol=1e-5)   # no bias correction: step = lr*0.1/sqrt(0.001)
+    assert abs(O.lr_schedule(5e-4, 500, 500000) - 5e-5) < 1e-12
+
+
+def test_oracle_trainer_runs_and_learns():
+    torch.manual_seed(0)
+    a = O.NerfArch()
+    tr = O.OracleTrainer(a, n_samples=8, n_importance=8, seed=3)
+    B = 16
+    o = torch.tensor([[0., 0., 4.]]).expand(B, 3).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(B, 3) * 0.1 + torch.tensor([0., 0., -1.]), dim=-1)
+    y = torch.rand(B, 3)
+    u = torch.rand(B, 8)
+    l0 = tr.step(o, d, y, u)
+    for _ in range(5):
+        l = tr.step(o, d, y, u)
+    assert l["loss_coarse"] < l0["loss_coarse"] and "loss_fine" in l
+    assert tr.m2 is tr.m                      # Q7 shared Adam state in quirk mode
