@@ -1,0 +1,191 @@
+/* nerf_hip.h -- C ABI of the MI355X-native NeRF hot path (libnerf_hip.so, gfx950).
+ *
+ * This is the drop-in boundary of SURVEY.md 8(b).  The reference
+ * (piljoong-jeong/nerf_meets_mlx) has no FFI layer of its own: its hot path is a set of
+ * Python functions over mlx arrays.  Each entry point below replaces the device work of
+ * one (or a fused group) of those functions; the citation after "replaces:" is the
+ * reference file:line.  The Python host package `nerf_meets_mlx_amd` binds these with
+ * ctypes and re-exports the reference's function names/signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) owned by the caller unless marked "host";
+ *     the library allocates nothing and keeps no state besides the last error string.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden
+ *     synchronisation, safe to capture into a hipGraph.
+ *   - tensors are dense row-major float32 unless stated; index tensors are int64.
+ *   - return value: 0 = NERF_OK, negative = NERF_E_*;  nerf_last_error() gives text.
+ *   - thread-compatible (not thread-safe); one process per GPU.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+
+#define NERF_OK 0
+#define NERF_E_NULL (-1)        /* required pointer is NULL                        */
+#define NERF_E_SHAPE (-2)       /* size / shape out of the supported range         */
+#define NERF_E_UNSUPPORTED (-3) /* architecture / mode not implemented in HIP      */
+#define NERF_E_HIP (-4)         /* HIP runtime error (launch failed, bad stream)   */
+#define NERF_E_RCCL (-5)        /* RCCL error                                      */
+
+int nerf_abi_version(void);
+const char* nerf_last_error(void);
+
+/* ---------------------------------------------------------------- rays (a1, a3, a4)
+ * rays are packed exactly like the reference's `rays_linear`
+ * (entrypoints/__test_nerf.py:60-82, rendering/render.py:319-328):
+ *   [o(3), d(3), near, far, viewdirs(3)] = 11 floats per ray.                        */
+#define NERF_RAY_STRIDE 11
+
+/* Distinct pseudo-random indices in [0, domain): out[i] = P_seed(offset + i) where P is a
+ * keyed bijection of [0, domain) (4-round Feistel + cycle walking).  Replaces
+ * `np.random.choice(H*W, N_rand, replace=False)` entrypoints/__test_nerf.py:229 with O(n)
+ * device work; requires offset + n <= domain.  Bit-exact vs the host mirror
+ * nerf_meets_mlx_amd.ops.index.pixel_permutation.                                  */
+int nerf_pixel_permutation(int64_t* out_idx, int64_t n, int64_t domain, uint64_t seed, uint64_t offset,
+                           void* stream);
+
+/* replaces: rendering/ray.py:7-35 get_rays + the (row, col) gather of
+ * entrypoints/__test_nerf.py:213-236 + viewdirs/near/far packing (:60-82).
+ * pixel_idx: [n] flat row-major pixel indices, or NULL for all H*W pixels in order
+ * (then n must equal H*W).  K: host, 9 DOUBLES row-major (the reference's K is a float64 numpy array,
+ * entrypoints/__test_nerf.py:170-174); c2w: host, 12 floats (3x4, row-major).  Directions are
+ * evaluated in float64 and rounded once to float32.
+ * coords (optional, may be NULL): [n,2] int64 (row, col) = (idx / W, idx % W).        */
+int nerf_ray_gen(const int64_t* pixel_idx, int64_t n, int H, int W, const double* K_host, const float* c2w_host,
+                 float near, float far, float* rays, int64_t* coords, void* stream);
+
+/* out[i, :] = src[idx[i], :]   (target pixel gather, entrypoints/__test_nerf.py:236)  */
+int nerf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t n, int channels, float* out,
+                     void* stream);
+
+/* replaces: rendering/ray.py:39-70 ndc_rays (in place on the o,d columns of `rays`)    */
+int nerf_ndc_rays(float* rays, int64_t n, int H, int W, float focal, float near, void* stream);
+
+/* ---------------------------------------------------------------- sampling (a5-a7, a15, a17)
+ * replaces: sampling/uniform.py:7-18, sampling/linear_disparity.py:8-19 (literal),
+ * sampling/__init__.py:10-31 add_noise_z (intended semantics).
+ * t_rand: [B,n] uniforms in [0,1) (caller's RNG), may be NULL when perturb <= 0.       */
+int nerf_sample_coarse(const float* rays, int64_t B, int n, int lindisp, float perturb, const float* t_rand,
+                       float* z, void* stream);
+
+/* replaces: sampling/__init__.py:101-177 sample_from_inverse_cdf_torch (u passed in
+ * instead of torch.rand) and the sort of entrypoints/__test_nerf.py:288 /
+ * rendering/render.py:225.  weights: [B,n] (the reference's [B,n,1] squeezed).
+ * Outputs (each may be NULL): z_new [B,N]; z_merged [B,n+N] ascending; cdf [B,n+1];
+ * inds [B,N] int64 = searchsorted(cdf, u, side="right") -- bit-exact given (cdf,u).
+ * Limits: 2 <= n <= 256, 1 <= N <= 512, n+N <= 768.                                   */
+int nerf_importance_sample(const float* z, const float* weights, const float* u, int64_t B, int n, int N, float eps,
+                           float* z_new, float* z_merged, float* cdf, int64_t* inds, void* stream);
+
+/* ---------------------------------------------------------------- encodings (a9, a10, a22, a23)
+ * replaces: models/embedding.py:23-90 Embedder.embed: [x, sin(f0 x), cos(f0 x), ...];
+ * freq_mode 0 = k^2 (reference quirk Q4), 1 = 2^k.  out: [M, D*(1+2*n_freqs)].        */
+int nerf_encode_freq(const float* x, int64_t M, int D, int n_freqs, int freq_mode, float* out, void* stream);
+
+/* replaces: encoding/sinusoidal.py:39-66: sin([s, s+pi/2]), s = x[...,None]*freq flattened
+ * dim-major/freq-minor; optional raw input appended at the end.  freqs: host float[n_freqs]
+ * (= 2^linspace(min_exp,max_exp,n), evaluated by the caller so that host and oracle
+ * share the table bit for bit; n_freqs <= 32).  out [M, 2*D*n_freqs (+D)].              */
+int nerf_encode_sinusoidal(const float* x, int64_t M, int D, int n_freqs, const float* freqs_host,
+                           int include_input, float* out, void* stream);
+
+/* replaces: encoding/spherical_harmonics.py:33-94; out [M,(degree+1)^2], 0<=degree<=4  */
+int nerf_sh_encode(const float* dirs, int64_t M, int degree, float* out, void* stream);
+
+/* replaces: encoding/multi_hash.py:61-136 (intended semantics).
+ * tables [L,T,F] float32, T = 2^log2_T, F in {1,2,4,8}; resolutions: host int[L];
+ * out [M, L*F].  backward: d_tables += scatter of d_out (float atomics).              */
+int nerf_hashgrid_forward(const float* x, int64_t M, const float* tables, int L, int log2_T, int F,
+                          const int* resolutions_host, float* out, void* stream);
+int nerf_hashgrid_backward(const float* x, int64_t M, const float* d_out, int L, int log2_T, int F,
+                           const int* resolutions_host, float* d_tables, void* stream);
+
+/* ---------------------------------------------------------------- compositing (a13)
+ * replaces: rendering/render.py:20-96 raw2outputs.  raw [B,n,4] = [rgb, sigma];
+ * noise [B,n] (N(0,1), caller's RNG) may be NULL when raw_noise_std == 0.
+ * Outputs: rgb [B,3], disp [B], acc [B], weights [B,n], depth [B] (any may be NULL
+ * except rgb).  One wavefront per ray, n <= 1024.                                      */
+int nerf_composite_forward(const float* raw, const float* z, const float* rays, int64_t B, int n,
+                           float raw_noise_std, const float* noise, int white_bkgd, float* rgb, float* disp,
+                           float* acc, float* weights, float* depth, void* stream);
+
+/* adjoint of the above (what mlx autograd computes for entrypoints/__test_nerf.py:132,142).
+ * d_rgb [B,3] required; d_acc [B], d_depth [B] optional (NULL = 0).  d_raw [B,n,4].     */
+int nerf_composite_backward(const float* raw, const float* z, const float* rays, int64_t B, int n,
+                            float raw_noise_std, const float* noise, int white_bkgd, const float* d_rgb,
+                            const float* d_acc, const float* d_depth, float* d_raw, void* stream);
+
+/* replaces: ops/metric.py:12-14 MSE and its gradient: loss_out[0] += sum((pred-target)^2)
+ * / count (caller zeroes it), d_pred = grad_scale * 2 (pred-target) / count.           */
+int nerf_mse_loss_grad(const float* pred, const float* target, int64_t count, float grad_scale, float* loss_out,
+                       float* d_pred, void* stream);
+
+/* ---------------------------------------------------------------- the MLP (a11, a12)
+ * replaces: models/NeRF.py:160-243 (NeRF.__init__/forward), :10-48 (run_model),
+ * models/embedding.py:4-21 (embed) for the architecture n_layers=8, width=256,
+ * skips=[4], use_viewdirs, in_pos=63, in_dir=27 (anything else: NERF_E_UNSUPPORTED).
+ *
+ * Parameter layout (float32, flat, `nerf_mlp_param_count` = 595844 elements), each
+ * layer as weight[out][in] row-major followed by bias[out]  (nn.Linear: x @ W^T + b):
+ *   pos0 [256x63] pos1..pos4 [256x256] pos5 [256x319] pos6 pos7 [256x256]
+ *   feature [256x256]  alpha [1x256]  dir0 [128x283]  rgb [3x128]
+ * Gradients use the same layout.                                                       */
+typedef struct nerf_mlp_arch {
+  int n_layers;     /* 8   */
+  int width;        /* 256 */
+  int in_pos;       /* 63  */
+  int in_dir;       /* 27  */
+  int skip_layer;   /* 4   */
+  int use_viewdirs; /* 1   */
+} nerf_mlp_arch;
+
+int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch);
+/* bytes of the packed bf16 MFMA-fragment image of the weights (forward + transposed
+ * backward images + fp32 biases) that the kernels stream; rebuilt after every update.   */
+int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch);
+int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, void* packed, void* stream);
+
+/* bytes of the activation / gradient-activation stores for M samples (training only)    */
+int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M);
+int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M);
+
+/* NeRF.forward(x): x [M, 90] already embedded -> out [M,4] = [rgb, alpha] raw.          */
+int nerf_mlp_forward(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M, float* out,
+                     void* stream);
+
+/* network_query_fn(pts, viewdirs, model) fused with pts = o + z d and both positional
+ * encodings (models/NeRF.py:75-80 + rendering/render.py:142,226): rays [B,11], z [B,n]
+ * -> raw [B,n,4].  freq_mode as nerf_encode_freq.  acts: NULL for inference, or a
+ * buffer of nerf_mlp_acts_bytes(B*n) that keeps the per-layer bf16 activations for
+ * nerf_mlp_backward.                                                                    */
+int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z, int64_t B,
+                     int n, int freq_mode, float* raw, void* acts, void* stream);
+
+/* Backward of nerf_query_fused w.r.t. the parameters (the reference gets this from
+ * mlx autograd: entrypoints/__test_nerf.py:132,142).  d_raw [M,4]; acts from the forward;
+ * dz: scratch of nerf_mlp_dz_bytes(M); grads [param_count] is OVERWRITTEN.              */
+int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
+                      int64_t M, void* dz, float* grads, void* stream);
+
+/* runtime selection of kernel variants (for A/B measurement): key "mlp_variant"        */
+int nerf_set_option(const char* key, int value);
+
+/* ---------------------------------------------------------------- optimiser (a21)
+ * replaces: mlx.optimizers.Adam.update as called at entrypoints/__test_nerf.py:134,144
+ * (mlx 0.7.0: no bias correction unless bias_correction != 0).  g is multiplied by
+ * grad_scale first (1/world_size after a sum all-reduce).                               */
+int nerf_adam_step(float* params, const float* grads, float* m, float* v, int64_t count, float lr, float beta1,
+                   float beta2, float eps, int bias_correction, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

@@ -1,0 +1,40 @@
+// Fused multi-tensor Adam over one flat float32 parameter buffer (a21 / K9).
+// HBM-bound: 28 B per parameter (read p,g,m,v; write p,m,v) = 16.7 MB per network.
+#include "common.h"
+
+namespace nerf {
+
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t count,
+                                                   float lr, float b1, float b2, float eps, float c1, float c2,
+                                                   float gscale) {
+  // mlx.optimizers.Adam (0.7.0): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+  // p = p - lr * m / (sqrt(v) + eps).  c1, c2 = 1 unless bias correction is requested.
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+  }
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" int nerf_adam_step(float* params, const float* grads, float* m, float* v, int64_t count, float lr,
+                              float beta1, float beta2, float eps, int bias_correction, int step, float grad_scale,
+                              void* stream) {
+  NERF_REQUIRE(params && grads && m && v, NERF_E_NULL, "nerf_adam_step: NULL pointer");
+  NERF_REQUIRE(count > 0, NERF_E_SHAPE, "nerf_adam_step: count must be > 0");
+  float c1 = 1.0f, c2 = 1.0f;
+  if (bias_correction) {
+    NERF_REQUIRE(step >= 1, NERF_E_SHAPE, "nerf_adam_step: bias correction needs step >= 1");
+    c1 = 1.0f / (1.0f - powf(beta1, (float)step));
+    c2 = 1.0f / (1.0f - powf(beta2, (float)step));
+  }
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count, 256)), dim3(256), 0, as_stream(stream), params, grads, m, v,
+                     count, lr, beta1, beta2, eps, c1, c2, grad_scale);
+  return check_launch("nerf_adam_step");
+}

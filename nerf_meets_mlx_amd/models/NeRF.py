@@ -1,0 +1,230 @@
+"""The 8x256 NeRF MLP, model factory and optimiser with the reference's call surface
+(`mlx_nerf/models/NeRF.py:10-243`), backed by the fused gfx950 kernels of csrc/mlp.hip.
+
+Parameters live in ONE flat float32 device buffer per network (layout: include/nerf_hip.h);
+the kernels stream a bf16 MFMA-fragment image of it (`packed`) that is rebuilt after every
+optimiser step.  `forward(x)` is the reference's `NeRF.forward` on embedded rows; the render
+path uses `query(rays, z)` which fuses pts = o + z d, both positional encodings and all 12
+layers into one launch.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from . import embedding
+
+_LAYERS = None
+
+
+def layer_shapes(n_layers=8, width=256, cin=63, cdir=27, skips=(4,), use_viewdirs=True, cout=4):
+    """(name, out, in) in flat-buffer order (include/nerf_hip.h "Parameter layout")."""
+    s = [("pos0", width, cin)]
+    for i in range(n_layers - 1):
+        s.append((f"pos{i + 1}", width, width + cin if i in skips else width))
+    if use_viewdirs:
+        s += [("feature", width, width), ("alpha", 1, width), ("dir0", width // 2, width + cdir), ("rgb", 3, width // 2)]
+    else:
+        s += [("output", cout, width)]
+    return s
+
+
+class NeRF:
+    """Same constructor arguments as `mlx_nerf/models/NeRF.py:160-199`.  Initialisation is
+    mlx.nn.Linear's: weight and bias ~ U(-1/sqrt(in), 1/sqrt(in)) (seeded numpy stream)."""
+
+    def __init__(self, n_layers=8, width_layers=256, channel_input=3, channel_input_views=3, channel_output=4,
+                 list_skip_connection_layers=[4], is_use_view_directions=False, device="cuda", seed: Optional[int] = None):
+        self.D, self.W = n_layers, width_layers
+        self.channel_input_pos, self.channel_input_dir = channel_input, channel_input_views
+        self.list_skip_connection_layers = list(list_skip_connection_layers)
+        self.is_use_view_directions = is_use_view_directions
+        self.device = torch.device(device)
+        self.shapes = layer_shapes(n_layers, width_layers, channel_input, channel_input_views,
+                                   tuple(self.list_skip_connection_layers), is_use_view_directions, channel_output)
+        self.n_params = sum(o * i + o for _, o, i in self.shapes)
+        self.arch = N.MlpArch(n_layers, width_layers, channel_input, channel_input_views,
+                              self.list_skip_connection_layers[0] if len(self.list_skip_connection_layers) == 1 else -1,
+                              int(bool(is_use_view_directions)))
+        rng = np.random.default_rng(seed)
+        chunks = []
+        for _, o, i in self.shapes:
+            k = 1.0 / math.sqrt(i)
+            chunks.append(rng.uniform(-k, k, size=(o, i)).astype(np.float32).reshape(-1))
+            chunks.append(rng.uniform(-k, k, size=(o,)).astype(np.float32))
+        self.params = torch.from_numpy(np.concatenate(chunks)).to(self.device)
+        self.grads = torch.zeros_like(self.params)
+        self._packed = None
+        self._dirty = True
+        self._ws: Dict[str, torch.Tensor] = {}
+
+    # ---- parameter views (the reference's tree: list_linears_pos / list_linears_dir / ... ) ----
+    def parameters(self) -> Dict[str, object]:
+        views, off = {}, 0
+        for name, o, i in self.shapes:
+            views[name] = {"weight": self.params[off:off + o * i].view(o, i), "bias": self.params[off + o * i:off + o * i + o]}
+            off += o * i + o
+        tree = {"list_linears_pos": [views[f"pos{l}"] for l in range(self.D)]}
+        if self.is_use_view_directions:
+            tree.update({"list_linears_dir": [views["dir0"]], "feature_linear": views["feature"],
+                         "alpha_linear": views["alpha"], "rgb_linear": views["rgb"]})
+        else:
+            tree["output_linear"] = views["output"]
+        return tree
+
+    def load_flat(self, flat: torch.Tensor):
+        assert flat.numel() == self.n_params
+        self.params.copy_(flat.to(self.device, torch.float32).reshape(-1))
+        self._dirty = True
+
+    def mark_updated(self):
+        self._dirty = True
+
+    # ---- packed bf16 fragment image ------------------------------------------------------------
+    def packed(self) -> torch.Tensor:
+        lib = N.lib()
+        if self._packed is None:
+            nbytes = lib.nerf_mlp_packed_bytes(C.byref(self.arch))
+            if nbytes < 0:
+                raise ValueError("libnerf_hip error -3: this NeRF architecture has no HIP kernel (supported: "
+                                 "n_layers=8, width=256, in=63+27, skips=[4], view directions on)")
+            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if self._dirty:
+            N.check(lib.nerf_mlp_pack(C.byref(self.arch), N.ptr(self.params), N.ptr(self._packed), N.stream()))
+            self._dirty = False
+        return self._packed
+
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+    # ---- NeRF.forward(x) on embedded rows (models/NeRF.py:201-243) -----------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = N.f32(x).reshape(-1, x.shape[-1])
+        out = torch.empty(x.shape[0], 4, dtype=torch.float32, device=x.device)
+        N.check(N.lib().nerf_mlp_forward(C.byref(self.arch), N.ptr(self.packed()), N.ptr(x), x.shape[0], N.ptr(out),
+                                         N.stream()))
+        return out
+
+    __call__ = forward
+
+    # ---- fused query: rays [B,11], z [B,n] -> raw [B,n,4] --------------------------------------
+    def query(self, rays: torch.Tensor, z: torch.Tensor, ref_quirks: bool = True, train: bool = False) -> torch.Tensor:
+        B, n = z.shape
+        raw = torch.empty(B, n, 4, dtype=torch.float32, device=z.device)
+        acts = None
+        if train:
+            acts = self._workspace("acts", N.lib().nerf_mlp_acts_bytes(C.byref(self.arch), B * n))
+            self._acts_M = B * n
+        N.check(N.lib().nerf_query_fused(C.byref(self.arch), N.ptr(self.packed()), N.ptr(rays), N.ptr(z), B, n,
+                                         0 if ref_quirks else 1, N.ptr(raw), N.ptr(acts), N.stream()))
+        return raw
+
+    def backward(self, d_raw: torch.Tensor) -> torch.Tensor:
+        """Parameter gradients of the last `query(..., train=True)`; overwrites self.grads."""
+        M = d_raw.numel() // 4
+        assert M == getattr(self, "_acts_M", -1), "backward() needs a matching query(train=True) first"
+        dz = self._workspace("dz", N.lib().nerf_mlp_dz_bytes(C.byref(self.arch), M))
+        N.check(N.lib().nerf_mlp_backward(C.byref(self.arch), N.ptr(self.packed()), N.ptr(self._ws["acts"]),
+                                          N.ptr(d_raw), M, N.ptr(dz), N.ptr(self.grads), N.stream()))
+        return self.grads
+
+
+class Adam:
+    """mlx.optimizers.Adam as the reference uses it (`models/NeRF.py:120`,
+    `entrypoints/__test_nerf.py:134,144`): ONE optimiser object steps both networks; MLX keys
+    its state by parameter-tree path, so coarse and fine (identical trees) share m and v
+     -- `shared_state=True`.  No bias correction in mlx 0.7.0."""
+
+    def __init__(self, learning_rate: float, betas=(0.9, 0.999), eps: float = 1e-8, bias_correction: bool = False,
+                 shared_state: bool = True):
+        self.learning_rate = learning_rate
+        self.betas, self.eps = betas, eps
+        self.bias_correction, self.shared_state = bias_correction, shared_state
+        self.state: Dict[object, List[torch.Tensor]] = {}
+        self.step_count: Dict[object, int] = {}
+
+    def update(self, model: NeRF, grads: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
+        g = model.grads if grads is None else grads
+        key = "shared" if self.shared_state else id(model)
+        if key not in self.state:
+            self.state[key] = [torch.zeros_like(model.params), torch.zeros_like(model.params)]
+            self.step_count[key] = 0
+        self.step_count[key] += 1
+        m, v = self.state[key]
+        N.check(N.lib().nerf_adam_step(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
+                                       float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
+                                       float(self.eps), int(self.bias_correction), self.step_count[key],
+                                       float(grad_scale), N.stream()))
+        model.mark_updated()
+
+
+def inference_wrapper_batch(model, chunk):
+    """`models/NeRF.py:10-22`."""
+    if chunk is None:
+        return model
+    return lambda x: torch.cat([model.forward(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)], dim=0)
+
+
+def run_model(pos, embed_pos, dir, embed_dir, model, netchunk=64 * 1024):
+    """Generic (unfused) query: embed all points, forward in `netchunk` slices
+    (`models/NeRF.py:25-48`).  Mirrors the rank assertion at :31."""
+    assert len(pos.shape) == 3, f"[ERROR] {pos.shape=} should have dimensions as: [n_rays, n_depth_samples, 3d position]!"
+    B, n = pos.shape[0], pos.shape[1]
+    x = embedding.embed(pos, embed_pos, dir, embed_dir)
+    out = inference_wrapper_batch(model, netchunk)(x)
+    return out.reshape(B, n, out.shape[-1])
+
+
+class NetworkQuery:
+    """`network_query_fn(inputs, viewdirs, model)` of `create_NeRF` (`models/NeRF.py:75-80`).
+    Calling it takes the generic path above; `.fused(rays, z, model)` is the one-launch form the
+    renderers in rendering/render.py use when they own the sampling."""
+
+    def __init__(self, embed_pos, embed_dir, netchunk, ref_quirks=True):
+        self.embed_pos, self.embed_dir, self.netchunk, self.ref_quirks = embed_pos, embed_dir, netchunk, ref_quirks
+
+    def __call__(self, inputs, viewdirs, model):
+        return run_model(inputs, self.embed_pos, viewdirs, self.embed_dir, model, netchunk=self.netchunk)
+
+    def fused(self, rays, z, model, train=False):
+        return model.query(rays, z, ref_quirks=self.ref_quirks, train=train)
+
+
+def create_NeRF(args, device="cuda", ref_quirks: bool = True, seed: Optional[int] = 0):
+    """Coarse (& fine) models, the query function, one Adam, and the render kwargs
+    (`models/NeRF.py:51-158`).  Returns (render_kwargs_train, render_kwargs_test, idx_iter, optimizer);
+    in quirk mode the two dicts are the SAME object like upstream (:152)."""
+    from ..rendering.render import render_rays, render_rays_eval
+    is_use_dir = bool(args.use_viewdirs)
+    embed_pos, ch_pos = embedding.get_embedder(args.multires, ref_quirks=ref_quirks)
+    embed_dir, ch_dir = embedding.get_embedder(args.multires_views, ref_quirks=ref_quirks) if is_use_dir else (None, 0)
+    output_ch = 5 if args.N_importance else 4
+    query = NetworkQuery(embed_pos, embed_dir, args.netchunk, ref_quirks)
+    mk = lambda d, w, s: NeRF(n_layers=d, width_layers=w, channel_input=ch_pos, channel_output=output_ch,
+                              list_skip_connection_layers=[4], channel_input_views=ch_dir,
+                              is_use_view_directions=is_use_dir, device=device, seed=s)
+    model_coarse = mk(args.netdepth, args.netwidth, seed)
+    model_fine = mk(args.netdepth_fine, args.netwidth_fine, None if seed is None else seed + 1) if args.N_importance > 0 else None
+    optimizer = Adam(learning_rate=args.lrate, betas=(0.9, 0.999), shared_state=ref_quirks)
+    kw = {
+        "use_viewdirs": is_use_dir, "white_bkgd": args.white_bkgd, "network_query_fn": query, "is_test": True,
+        "render_rays_func": render_rays, "network_coarse": model_coarse, "n_depth_samples": args.n_depth_samples,
+        "network_fine": model_fine, "perturb": args.perturb, "raw_noise_std": args.raw_noise_std,
+        "N_importance": args.N_importance,
+    }
+    if args.dataset_type != "llff" or args.no_ndc:
+        kw["ndc"] = False
+        kw["lindisp"] = args.lindisp
+    kw_test = kw if ref_quirks else dict(kw)
+    kw_test["perturb"] = False
+    kw_test["raw_noise_std"] = 0
+    kw_test["is_test"] = False
+    kw_test["render_rays_func"] = render_rays_eval
+    return kw, kw_test, 0, optimizer

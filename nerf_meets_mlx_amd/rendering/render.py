@@ -1,0 +1,157 @@
+"""Volume rendering with the reference's call surface (`mlx_nerf/rendering/render.py`):
+
+    render(...) -> batchify_rays(...) -> render_rays / render_rays_eval(...) -> raw2outputs(...)
+
+Every stage is one HIP launch: coarse depths (`nerf_sample_coarse`), the fused
+PE + MLP query (`nerf_query_fused`), alpha compositing (`nerf_composite_forward`) and the
+importance sampler + merge (`nerf_importance_sample`).  The reference's numpy ray-gen and the
+torch-CPU sampler round trip (:215-223) do not exist here.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from .. import _native as N
+from .. import sampling
+from . import ray
+
+
+def composite(raw, z_vals, rays, raw_noise_std=0.0, white_bkgd=False, noise=None, need_weights=True):
+    """raw [B,n,4], z [B,n], packed rays [B,11] -> (rgb [B,3], disp [B], acc [B], weights [B,n], depth [B])."""
+    B, n = z_vals.shape
+    dev = raw.device
+    rgb = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    disp = torch.empty(B, dtype=torch.float32, device=dev)
+    acc = torch.empty(B, dtype=torch.float32, device=dev)
+    depth = torch.empty(B, dtype=torch.float32, device=dev)
+    weights = torch.empty(B, n, dtype=torch.float32, device=dev) if need_weights else None
+    if raw_noise_std > 0.0 and noise is None:
+        noise = torch.randn(B, n, dtype=torch.float32, device=dev)            # mx.random.normal (:42)
+    N.check(N.lib().nerf_composite_forward(N.ptr(raw), N.ptr(z_vals), N.ptr(rays), B, n, float(raw_noise_std),
+                                           N.ptr(noise) if raw_noise_std > 0.0 else None, int(bool(white_bkgd)),
+                                           N.ptr(rgb), N.ptr(disp), N.ptr(acc), N.ptr(weights), N.ptr(depth), N.stream()))
+    return rgb, disp, acc, weights, depth
+
+
+def composite_backward(raw, z_vals, rays, d_rgb, white_bkgd=False, d_acc=None, d_depth=None, raw_noise_std=0.0,
+                       noise=None):
+    """d_raw [B,n,4] for upstream gradients of rgb (and optionally acc / depth)."""
+    B, n = z_vals.shape
+    d_raw = torch.empty(B, n, 4, dtype=torch.float32, device=raw.device)
+    N.check(N.lib().nerf_composite_backward(N.ptr(raw), N.ptr(z_vals), N.ptr(rays), B, n, float(raw_noise_std),
+                                            N.ptr(noise) if raw_noise_std > 0.0 else None, int(bool(white_bkgd)),
+                                            N.ptr(d_rgb), N.ptr(d_acc), N.ptr(d_depth), N.ptr(d_raw), N.stream()))
+    return d_raw
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None):
+    """`rendering/render.py:20-96`: returns (rgb_map [B,3], disp_map [B,1], acc_map [B,1],
+    weights [B,n,1], depth_map [B,1]) -- shapes as upstream."""
+    raw, z_vals = N.f32(raw), N.f32(z_vals)
+    B = z_vals.shape[0]
+    rays = torch.zeros(B, 11, dtype=torch.float32, device=raw.device)
+    rays[:, 3:6] = rays_d
+    rgb, disp, acc, w, depth = composite(raw, z_vals, rays, float(raw_noise_std), white_bkgd, noise)
+    return rgb, disp[:, None], acc[:, None], w[..., None], depth[:, None]
+
+
+def decompose_ray_batch(rays_batch_linear, is_time_included: bool = False):
+    """`rendering/render.py:98-110`."""
+    r = rays_batch_linear
+    rays_o, rays_d = r[:, 0:3], r[:, 3:6]
+    bounds = r[..., 6:8 + int(is_time_included)].reshape(-1, 1, 2 + int(is_time_included))
+    near, far = bounds[..., 0], bounds[..., 1]
+    frame_time = bounds[..., 2] if is_time_included else None
+    return rays_o, rays_d, near, far, r[:, -3:], frame_time
+
+
+def _query(network_query_fn, rays, z, model):
+    if hasattr(network_query_fn, "fused") and hasattr(model, "query"):
+        return network_query_fn.fused(rays, z, model)
+    o, d, _, _, viewdirs, _ = decompose_ray_batch(rays)
+    pos = o[..., None, :] + z[..., :, None] * d[..., None, :]
+    return network_query_fn(pos, viewdirs, model)
+
+
+def _coarse_pass(rays, network_coarse, network_query_fn, n_depth_samples, retraw, lindisp, perturb, white_bkgd,
+                 raw_noise_std):
+    rays = N.f32(rays)
+    z_vals = sampling.sample_coarse(rays, n_depth_samples, lindisp=lindisp, perturb=float(perturb or 0.0))
+    raw = _query(network_query_fn, rays, z_vals, network_coarse)
+    rgb, disp, acc, weights, depth = composite(raw, z_vals, rays, float(raw_noise_std or 0.0), white_bkgd)
+    ret = {}
+    if retraw:
+        ret["raw"] = raw
+    ret.update({"rgb_map": rgb, "disp_map": disp[:, None], "acc_map": acc[:, None], "rgb_coarse": rgb,
+                "disp_coarse": disp[:, None], "acc_coarse": acc[:, None], "z_vals": z_vals,
+                "weights": weights[..., None]})
+    return rays, ret
+
+
+def render_rays(rays_batch_linear, network_coarse, network_query_fn, n_depth_samples, retraw=False, lindisp=False,
+                perturb=0.0, N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.0, verbose=False,
+                pytest=False, **kwargs):
+    """Coarse-only pass (`rendering/render.py:112-162`); ignores N_importance / network_fine like upstream."""
+    return _coarse_pass(rays_batch_linear, network_coarse, network_query_fn, n_depth_samples, retraw, lindisp, perturb,
+                        white_bkgd, raw_noise_std)[1]
+
+
+def render_rays_eval(rays_batch_linear, network_coarse, network_query_fn, n_depth_samples, retraw=False, lindisp=False,
+                     perturb=0.0, N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.0,
+                     verbose=False, pytest=False, u=None, **kwargs):
+    """Coarse pass + importance sampling + sort + second pass (`rendering/render.py:164-241`).
+    Upstream always runs the second pass (with network_coarse when there is no fine net, Q19);
+    with N_importance == 0 that pass would re-evaluate identical samples, so it is skipped."""
+    rays, ret = _coarse_pass(rays_batch_linear, network_coarse, network_query_fn, n_depth_samples, retraw, lindisp,
+                             perturb, white_bkgd, raw_noise_std)
+    if N_importance and N_importance > 0:
+        _, z_fine = sampling.importance_sample(ret["z_vals"], ret["weights"], N_importance, u=u)
+        run_fn = network_fine if network_fine else network_coarse
+        raw = _query(network_query_fn, rays, z_fine, run_fn)
+        rgb, disp, acc, _, _ = composite(raw, z_fine, rays, float(raw_noise_std or 0.0), white_bkgd, need_weights=False)
+        ret["rgb_map"], ret["disp_map"], ret["acc_map"] = rgb, disp[:, None], acc[:, None]
+    return ret
+
+
+def batchify_rays(rays_linear, chunk=1024 * 32, **kwargs):
+    """`rendering/render.py:243-266`."""
+    render_rays_func = kwargs["render_rays_func"]
+    u_all = kwargs.pop("u", None)
+    results: Dict[str, list] = {}
+    for i in range(0, rays_linear.shape[0], chunk):
+        extra = {} if u_all is None else {"u": u_all[i:i + chunk]}
+        out = render_rays_func(rays_linear[i:i + chunk], **kwargs, **extra)
+        for k, v in out.items():
+            results.setdefault(k, []).append(v)
+    return {k: torch.cat(v, dim=0) for k, v in results.items()}
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.0, far=1.0, use_viewdirs=False,
+           c2w_staticcam=None, device="cuda", **kwargs):
+    """`rendering/render.py:268-345`: returns [rgb_map, disp_map, acc_map, extras_dict] reshaped to
+    the ray grid.  Ray generation runs on the device (no host image of rays)."""
+    if c2w is not None:
+        packed = ray.gen_rays(H, W, K, c2w, near, far, None, device)
+        rays_shape = (H, W, 3)
+        if c2w_staticcam is not None:                         # viewdirs from c2w, geometry from the static camera
+            st = ray.gen_rays(H, W, K, c2w_staticcam, near, far, None, device)
+            st[:, 8:11] = packed[:, 8:11]
+            packed = st
+    else:
+        rays_o, rays_d = rays
+        rays_shape = tuple(rays_d.shape)
+        rays_o, rays_d = N.f32(rays_o).reshape(-1, 3), N.f32(rays_d).reshape(-1, 3)
+        packed = torch.empty(rays_o.shape[0], 11, dtype=torch.float32, device=rays_o.device)
+        packed[:, 0:3], packed[:, 3:6] = rays_o, rays_d
+        packed[:, 6], packed[:, 7] = near, far
+        packed[:, 8:11] = rays_d / torch.linalg.norm(rays_d, dim=-1, keepdim=True)
+    if ndc:
+        o, d = ray.ndc_rays(H, W, K[0][0], 1.0, packed[:, 0:3].contiguous(), packed[:, 3:6].contiguous())
+        packed[:, 0:3], packed[:, 3:6] = o, d
+    if not use_viewdirs:
+        raise ValueError("only the view-dependent model is a supported volume path (SURVEY Q16)")
+    res = batchify_rays(packed, chunk, **kwargs)
+    for k, v in res.items():
+        res[k] = v.reshape(tuple(rays_shape[:-1]) + tuple(v.shape[1:]))
+    keys = ["rgb_map", "disp_map", "acc_map"]
+    return [res[k] for k in keys] + [{k: v for k, v in res.items() if k not in keys}]

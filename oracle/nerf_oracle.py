@@ -87,16 +87,25 @@ def decompose_ray_batch(rays):
 # a5 / a6 / a7  depth sampling
 # --------------------------------------------------------------------------------------
 
+def mlx_linspace(start: float, stop: float, num: int, dtype=torch.float32):
+    """mx.linspace as published for mlx 0.7.0 (mlx/ops.cpp, not in /root/reference):
+    arange(0,num,float32) * float32((stop-start)/(num-1)) + start.  Differs from
+    torch.linspace (symmetric formula) by <= 1 ulp; UNPINNED assumption."""
+    step = np.float32((stop - start) / (num - 1)) if dtype == torch.float32 else (stop - start) / (num - 1)
+    seq = torch.arange(0, num, dtype=dtype)
+    return seq * torch.tensor(step, dtype=dtype) + torch.tensor(start, dtype=dtype)
+
+
 def sample_z_uniform(near, far, n: int):
     """sampling/uniform.py:7-18: t = linspace(0,1,n); z = near*(1-t) + far*t."""
-    t = torch.linspace(0.0, 1.0, n, dtype=near.dtype)
+    t = mlx_linspace(0.0, 1.0, n, dtype=near.dtype)
     return near * (1.0 - t) + far * t
 
 
 def sample_z_lindisp(near, far, n: int):
     """sampling/linear_disparity.py:8-19, restated literally (both
     end points evaluate to 1/(x + inf) = 0; this is NOT the standard formula)."""
-    t = torch.linspace(0.0, 1.0, n, dtype=near.dtype)
+    t = mlx_linspace(0.0, 1.0, n, dtype=near.dtype)
     return 1.0 / (1.0 / (near * (1.0 - t)) + 1.0 / (far * t))
 
 
@@ -144,14 +153,19 @@ def embed(pos, dirs, L_pos: int = 10, L_dir: int = 4, ref_quirks: bool = True):
     return torch.cat([e_pos, embedder(d, L_dir, ref_quirks)], dim=-1)
 
 
+def sinusoidal_freqs(n_freqs: int, min_exp=None, max_exp=None, dtype=torch.float32):
+    """encoding/sinusoidal.py:27-28,49-51: 2 ** linspace(min_exp or 0, max_exp or n-1, n)."""
+    mn = min_exp if min_exp else 0.0
+    mx_ = max_exp if max_exp else float(n_freqs - 1)
+    return 2.0 ** mlx_linspace(mn, mx_, n_freqs, dtype=dtype)
+
+
 def sinusoidal_encoding(x, n_freqs: int, min_exp: Optional[float] = None, max_exp: Optional[float] = None,
                         include_input: bool = False):
     """encoding/sinusoidal.py:13-66: freq = 2 ** linspace(min,max,n); s = x[...,None]*freq
     reshaped dim-major/freq-minor; out = sin(concat[s, s + pi/2]); raw input appended
     at the END.  (`min_exp if min_exp else 0.0`, `max_exp if max_exp else n-1`: :27-28)."""
-    mn = min_exp if min_exp else 0.0
-    mx_ = max_exp if max_exp else float(n_freqs - 1)
-    freq = 2.0 ** torch.linspace(mn, mx_, n_freqs, dtype=x.dtype)
+    freq = sinusoidal_freqs(n_freqs, min_exp, max_exp, x.dtype)
     s = (x[..., None] * freq).reshape(x.shape[0], -1)
     out = torch.sin(torch.cat([s, s + math.pi / 2.0], dim=-1))
     if include_input:
@@ -213,9 +227,11 @@ def hash_coords(c: torch.Tensor, T: int) -> torch.Tensor:
 
 
 def hashgrid_encoding(x, tables: torch.Tensor, resolutions: Sequence[int]):
-    """encoding/multi_hash.py:79-136, intended semantics.  x [B,3]; tables [L,T,F].
-    x_l = x*N_l; corners from ceil/floor per axis (no +0.5, every level hashed);
-    offset = x_l - floor(x_l) weights the CEIL corner (:122-131)."""
+    """encoding/multi_hash.py:79-136, intended semantics (the committed class cannot run:
+    Q13).  x [B,3]; tables [L,T,F].  x_l = x*N_l; corners from ceil/floor per axis (no
+    +0.5, every level hashed); offset = x_l - floor(x_l) weights the CEIL corner; the
+    nested lerps are restated literally (:122-131):
+      grid_0=(c,c,c) 1=(c,f,c) 2=(f,f,c) 3=(f,c,c) 4=(c,c,f) 5=(c,f,f) 6=(f,f,f) 7=(f,c,f)."""
     L, T, F = tables.shape
     outs = []
     for l in range(L):
@@ -224,19 +240,21 @@ def hashgrid_encoding(x, tables: torch.Tensor, resolutions: Sequence[int]):
         ce = torch.ceil(xs)
         off = xs - fl
         fl_i, ce_i = fl.to(torch.int64), ce.to(torch.int64)
-        acc = torch.zeros(x.shape[0], F, dtype=x.dtype)
-        for cz in (0, 1):
-            for cy in (0, 1):
-                for cx in (0, 1):
-                    cx_i = ce_i[:, 0] if cx else fl_i[:, 0]
-                    cy_i = ce_i[:, 1] if cy else fl_i[:, 1]
-                    cz_i = ce_i[:, 2] if cz else fl_i[:, 2]
-                    idx = hash_coords(torch.stack([cx_i, cy_i, cz_i], -1), T)
-                    wx = off[:, 0] if cx else 1 - off[:, 0]
-                    wy = off[:, 1] if cy else 1 - off[:, 1]
-                    wz = off[:, 2] if cz else 1 - off[:, 2]
-                    acc = acc + tables[l][idx] * (wx * wy * wz)[:, None]
-        outs.append(acc)
+
+        def corner(cx, cy, cz):
+            g = torch.stack([ce_i[:, 0] if cx else fl_i[:, 0], ce_i[:, 1] if cy else fl_i[:, 1],
+                             ce_i[:, 2] if cz else fl_i[:, 2]], -1)
+            return tables[l][hash_coords(g, T)]
+        h0, h1, h2, h3 = corner(1, 1, 1), corner(1, 0, 1), corner(0, 0, 1), corner(0, 1, 1)
+        h4, h5, h6, h7 = corner(1, 1, 0), corner(1, 0, 0), corner(0, 0, 0), corner(0, 1, 0)
+        ox, oy, oz = off[:, 0:1], off[:, 1:2], off[:, 2:3]
+        h03 = h0 * ox + h3 * (1 - ox)
+        h12 = h1 * ox + h2 * (1 - ox)
+        h56 = h5 * ox + h6 * (1 - ox)
+        h47 = h4 * ox + h7 * (1 - ox)
+        h0312 = h03 * oy + h12 * (1 - oy)
+        h4756 = h47 * oy + h56 * (1 - oy)
+        outs.append(h0312 * oz + h4756 * (1 - oz))
     return torch.cat(outs, dim=-1)
 
 
