@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- train+render rays/s of the MI355X-native NeRF hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one training iteration of the reference loop (entrypoints/__test_nerf.py:200-305:
+N_rand rays, coarse 64 + fine 64+128 samples, forward + backward + Adam for both networks) PLUS
+one render chunk (rendering/render.py:243-266: `chunk` = 32768 rays through coarse + importance
+sampling + fine) on the synthetic Lego-like 800x800 scene (BASELINE.json configs[2]).  Inputs are
+resident in HBM before the timed region.  value = (train rays + render rays) of ALL ranks / time;
+rays shard across ranks with no data-path collective except the gradient all-reduce (weak scaling).
+
+The JSON line also carries `roofline` for the dominant kernel (the fused MLP forward of the render
+fine pass, MFMA-bound, timed with events on the launch stream inside the timed region) and
+`cpu_baseline` (the CPU oracle = op-for-op restatement of the reference, timed on this box's host
+cores on a bounded sample of the same workload; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE_FWD = 2 * 593408          # SURVEY 8d / BASELINE.md section 2
+BF16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-rand", type=int, default=4096, help="training rays per GPU per step (argparse default of the reference)")
+    ap.add_argument("--render-rays", type=int, default=32768, help="rays per render chunk per GPU per step")
+    ap.add_argument("--hw", type=int, default=800)
+    ap.add_argument("--train-images", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mlp-variant", type=int, default=0)
+    args = ap.parse_args()
+
+    from nerf_meets_mlx_amd import _native, parallel
+    from nerf_meets_mlx_amd.dataset import synthetic
+    from nerf_meets_mlx_amd.engine.trainer import Trainer
+    from nerf_meets_mlx_amd.rendering import ray
+
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _native.check(_native.lib().nerf_set_option(b"mlp_variant", args.mlp_variant))
+
+    H = W = args.hw
+    imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, args.train_images, seed=0, device=dev)
+    tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=128, seed=0, device=dev,
+                 chunk=args.render_rays)
+    # render chunk of this rank: a contiguous slice of a render pose's pixel list, resident on the device
+    lo, _ = parallel.shard_range(H * W, rank, world)
+    lo = min(lo, H * W - args.render_rays)
+    ridx = torch.arange(lo, lo + args.render_rays, device=dev, dtype=torch.int64)
+    rrays = ray.gen_rays(H, W, K, rposes[40][:3, :4], 2.0, 6.0, ridx)
+    ev = {"t": []}
+
+    def timed_fine_query(r, zf):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        raw = tr.fine.query(r, zf, ref_quirks=True)
+        e1.record()
+        ev["t"].append((e0, e1))
+        return raw
+
+    from nerf_meets_mlx_amd import sampling
+    from nerf_meets_mlx_amd.rendering import render
+
+    def render_chunk():
+        z = sampling.sample_coarse(rrays, 64)
+        raw = tr.coarse.query(rrays, z)
+        _, _, _, w, _ = render.composite(raw, z, rrays, 0.0, True)
+        u = torch.rand(rrays.shape[0], 128, device=dev, generator=tr.gen)
+        _, zf = sampling.importance_sample(z, w, 128, u=u)
+        raw = timed_fine_query(rrays, zf)
+        return render.composite(raw, zf, rrays, 0.0, True, need_weights=False)[0]
+
+    def step():
+        out = tr.train_step()
+        rgb = render_chunk()
+        return out, rgb
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev["t"].clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, rgb = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    assert torch.isfinite(rgb).all() and torch.isfinite(out["loss_coarse"]).all()
+
+    rays_per_step = (args.n_rand + args.render_rays) * world
+    value = rays_per_step * args.steps / dt
+    # dominant kernel: fused MLP forward over render_rays x 192 samples
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["t"]]))
+    flop = FLOP_PER_SAMPLE_FWD * args.render_rays * 192
+    achieved = flop / (k_ms * 1e-3) / 1e12
+    line = {
+        "metric": "train+render rays/sec on Lego 800x800 (synthetic), coarse+fine 64+128",
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"configs[2]: Lego {H}x{W} coarse+fine NeRF (64+128 importance samples), "
+                               f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU",
+                   "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
+        "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
+        "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel (render fine pass)", "achieved": achieved,
+                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * 192},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (op-for-op torch-CPU restatement of the reference path) on a bounded sample
+    of the same workload: same train:render ray ratio, small batch, all host cores."""
+    from oracle import nerf_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    arch = O.NerfArch()
+    tr = O.OracleTrainer(arch, 64, 128, seed=0)
+    b_train, b_render, steps = 64, 512, 2
+    g = torch.Generator().manual_seed(0)
+    o = torch.nn.functional.normalize(torch.randn(b_render, 3, generator=g), dim=-1) * 4.0
+    d = -o / 4.0 + 0.2 * torch.randn(b_render, 3, generator=g)
+    y = torch.rand(b_train, 3, generator=g)
+    pc, pf = (O.unflatten_params(arch, tr.pc.detach()), O.unflatten_params(arch, tr.pf.detach()))
+
+    def one():
+        tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, 128, generator=g))
+        with torch.no_grad():
+            O.render_rays_eval(arch, pc, pf, O.pack_rays(o, d, 2.0, 6.0), 64, 128, torch.rand(b_render, 128, generator=g), True)
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": (b_train + b_render) * steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of (train {b_train} rays + render {b_render} rays), coarse+fine 64+128, torch-CPU fp32 oracle",
+            "seconds": dt}
+
+
+if __name__ == "__main__":
+    main()

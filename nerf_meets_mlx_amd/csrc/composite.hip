@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
     if (lane == 0) {
       if (white) { sr = sr + (1.0f - sa); sg = sg + (1.0f - sa); sb = sb + (1.0f - sa); }   // render.py:91-92
       rgb[ray * 3 + 0] = sr; rgb[ray * 3 + 1] = sg; rgb[ray * 3 + 2] = sb;
-      if (disp) disp[ray] = 1.0f / fmaxf(1e-10f, sd / sa);                                 // render.py:85-88 (0/0 -> NaN, Q11)
+      if (disp) {                                     // render.py:85-88; maximum() propagates NaN: acc == 0 -> NaN (Q11)
+        const float q = sd / sa;
+        disp[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+      }
       if (acc) acc[ray] = sa;
       if (depth) depth[ray] = sd;
     }
@@ -156,8 +159,9 @@ using namespace nerf;
 extern "C" int nerf_composite_forward(const float* raw, const float* z, const float* rays, int64_t B, int n,
                                       float raw_noise_std, const float* noise, int white_bkgd, float* rgb, float* disp,
                                       float* acc, float* weights, float* depth, void* stream) {
-  NERF_REQUIRE(raw && z && rays && rgb, NERF_E_NULL, "nerf_composite_forward: raw/z/rays/rgb is NULL");
   NERF_REQUIRE(n >= 1 && n <= 1024, NERF_E_SHAPE, "nerf_composite_forward: need 1 <= n <= 1024 (n=%d)", n);
+  if (B <= 0) return NERF_OK;
+  NERF_REQUIRE(raw && z && rays && rgb, NERF_E_NULL, "nerf_composite_forward: raw/z/rays/rgb is NULL");
   NERF_REQUIRE(raw_noise_std <= 0.0f || noise, NERF_E_NULL, "nerf_composite_forward: raw_noise_std > 0 needs noise");
   if (B <= 0) return NERF_OK;
   const dim3 g((unsigned)((B + 3) / 4 > 8192 ? 8192 : (B + 3) / 4)), b(256);
@@ -171,8 +175,9 @@ extern "C" int nerf_composite_forward(const float* raw, const float* z, const fl
 extern "C" int nerf_composite_backward(const float* raw, const float* z, const float* rays, int64_t B, int n,
                                        float raw_noise_std, const float* noise, int white_bkgd, const float* d_rgb,
                                        const float* d_acc, const float* d_depth, float* d_raw, void* stream) {
-  NERF_REQUIRE(raw && z && rays && d_rgb && d_raw, NERF_E_NULL, "nerf_composite_backward: NULL pointer");
   NERF_REQUIRE(n >= 1 && n <= 1024, NERF_E_SHAPE, "nerf_composite_backward: need 1 <= n <= 1024 (n=%d)", n);
+  if (B <= 0) return NERF_OK;
+  NERF_REQUIRE(raw && z && rays && d_rgb && d_raw, NERF_E_NULL, "nerf_composite_backward: NULL pointer");
   NERF_REQUIRE(raw_noise_std <= 0.0f || noise, NERF_E_NULL, "nerf_composite_backward: raw_noise_std > 0 needs noise");
   if (B <= 0) return NERF_OK;
   const dim3 g((unsigned)((B + 3) / 4 > 8192 ? 8192 : (B + 3) / 4)), b(256);

@@ -168,6 +168,7 @@ using namespace nerf;
 
 extern "C" int nerf_encode_freq(const float* x, int64_t M, int D, int n_freqs, int freq_mode, float* out,
                                 void* stream) {
+  if (M <= 0) return NERF_OK;
   NERF_REQUIRE(x && out, NERF_E_NULL, "nerf_encode_freq: x/out is NULL");
   NERF_REQUIRE(D >= 1 && D <= 8 && n_freqs >= 0 && n_freqs <= 16, NERF_E_SHAPE, "nerf_encode_freq: bad D/n_freqs");
   NERF_REQUIRE(freq_mode == 0 || freq_mode == 1, NERF_E_UNSUPPORTED, "nerf_encode_freq: freq_mode must be 0 or 1");
@@ -179,6 +180,7 @@ extern "C" int nerf_encode_freq(const float* x, int64_t M, int D, int n_freqs, i
 
 extern "C" int nerf_encode_sinusoidal(const float* x, int64_t M, int D, int n_freqs, const float* freqs_host,
                                       int include_input, float* out, void* stream) {
+  if (M <= 0) return NERF_OK;
   NERF_REQUIRE(x && out && freqs_host, NERF_E_NULL, "nerf_encode_sinusoidal: NULL pointer");
   NERF_REQUIRE(D >= 1 && n_freqs >= 1 && n_freqs <= 32, NERF_E_SHAPE, "nerf_encode_sinusoidal: need 1<=n_freqs<=32");
   if (M <= 0) return NERF_OK;
@@ -191,9 +193,9 @@ extern "C" int nerf_encode_sinusoidal(const float* x, int64_t M, int D, int n_fr
 }
 
 extern "C" int nerf_sh_encode(const float* dirs, int64_t M, int degree, float* out, void* stream) {
-  NERF_REQUIRE(dirs && out, NERF_E_NULL, "nerf_sh_encode: NULL pointer");
   NERF_REQUIRE(degree >= 0 && degree <= 4, NERF_E_SHAPE, "nerf_sh_encode: n_degrees=%d must be in range [0, 4]", degree);
   if (M <= 0) return NERF_OK;
+  NERF_REQUIRE(dirs && out, NERF_E_NULL, "nerf_sh_encode: NULL pointer");
   hipLaunchKernelGGL(sh_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), dirs, M, degree, out);
   return check_launch("nerf_sh_encode");
 }

@@ -125,8 +125,9 @@ extern "C" int nerf_pixel_permutation(int64_t* out_idx, int64_t n, int64_t domai
 
 extern "C" int nerf_ray_gen(const int64_t* pixel_idx, int64_t n, int H, int W, const double* K, const float* c2w,
                             float near, float far, float* rays, int64_t* coords, void* stream) {
-  NERF_REQUIRE(K && c2w && rays, NERF_E_NULL, "nerf_ray_gen: K/c2w/rays is NULL");
   NERF_REQUIRE(H > 0 && W > 0 && n >= 0, NERF_E_SHAPE, "nerf_ray_gen: bad H/W/n");
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(K && c2w && rays, NERF_E_NULL, "nerf_ray_gen: K/c2w/rays is NULL");
   NERF_REQUIRE(pixel_idx || n == (int64_t)H * W, NERF_E_SHAPE, "nerf_ray_gen: pixel_idx NULL requires n == H*W");
   if (n == 0) return NERF_OK;
   Cam cam;
@@ -142,17 +143,18 @@ extern "C" int nerf_ray_gen(const int64_t* pixel_idx, int64_t n, int H, int W, c
 
 extern "C" int nerf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t n, int channels,
                                 float* out, void* stream) {
-  NERF_REQUIRE(src && idx && out, NERF_E_NULL, "nerf_gather_rows: NULL pointer");
-  NERF_REQUIRE(n >= 0 && channels > 0 && n_src > 0, NERF_E_SHAPE, "nerf_gather_rows: bad sizes");
+  NERF_REQUIRE(n >= 0 && channels > 0, NERF_E_SHAPE, "nerf_gather_rows: bad sizes");
   if (n == 0) return NERF_OK;
+  NERF_REQUIRE(src && idx && out, NERF_E_NULL, "nerf_gather_rows: NULL pointer");
+  NERF_REQUIRE(n_src > 0, NERF_E_SHAPE, "nerf_gather_rows: empty source");
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * channels, 256)), dim3(256), 0, as_stream(stream), src, idx,
                      n, channels, out);
   return check_launch("nerf_gather_rows");
 }
 
 extern "C" int nerf_ndc_rays(float* rays, int64_t n, int H, int W, float focal, float near, void* stream) {
-  NERF_REQUIRE(rays, NERF_E_NULL, "nerf_ndc_rays: rays is NULL");
   if (n <= 0) return NERF_OK;
+  NERF_REQUIRE(rays, NERF_E_NULL, "nerf_ndc_rays: rays is NULL");
   hipLaunchKernelGGL(ndc_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), rays, n,
                      -focal / (0.5f * W), -focal / (0.5f * H), near);
   return check_launch("nerf_ndc_rays");

@@ -130,8 +130,9 @@ using namespace nerf;
 
 extern "C" int nerf_sample_coarse(const float* rays, int64_t B, int n, int lindisp, float perturb,
                                   const float* t_rand, float* z, void* stream) {
-  NERF_REQUIRE(rays && z, NERF_E_NULL, "nerf_sample_coarse: rays/z is NULL");
   NERF_REQUIRE(B >= 0 && n >= 2, NERF_E_SHAPE, "nerf_sample_coarse: need n >= 2 (n=%d)", n);
+  if (B == 0) return NERF_OK;
+  NERF_REQUIRE(rays && z, NERF_E_NULL, "nerf_sample_coarse: rays/z is NULL");
   NERF_REQUIRE(perturb <= 0.0f || t_rand, NERF_E_NULL, "nerf_sample_coarse: perturb > 0 needs t_rand");
   if (B == 0) return NERF_OK;
   const float step = (float)((1.0 - 0.0) / (double)(n - 1));
@@ -143,10 +144,10 @@ extern "C" int nerf_sample_coarse(const float* rays, int64_t B, int n, int lindi
 extern "C" int nerf_importance_sample(const float* z, const float* weights, const float* u, int64_t B, int n, int N,
                                       float eps, float* z_new, float* z_merged, float* cdf, int64_t* inds,
                                       void* stream) {
-  NERF_REQUIRE(z && weights && u, NERF_E_NULL, "nerf_importance_sample: z/weights/u is NULL");
   NERF_REQUIRE(n >= 2 && n <= 256 && N >= 1 && N <= 512 && n + N <= 768, NERF_E_SHAPE,
                "nerf_importance_sample: unsupported n=%d N=%d (2<=n<=256, 1<=N<=512)", n, N);
   if (B <= 0) return NERF_OK;
+  NERF_REQUIRE(z && weights && u, NERF_E_NULL, "nerf_importance_sample: z/weights/u is NULL");
   const int per_wave = (n + 1) * 2 + ((n + N + 3) & ~3);
   const size_t lds = (size_t)per_wave * 4 * sizeof(float);
   const int grid = (int)((B + 3) / 4 > 256 * 8 ? 256 * 8 : (B + 3) / 4);

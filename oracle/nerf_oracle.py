@@ -374,7 +374,7 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std: float = 0.0, white_bkgd: boo
     x = (deltas * sigma)[..., None]                                  # [B,n,1]
     alphas = 1.0 - torch.exp(-torch.relu(x))
     T = torch.cumsum(x[..., :-1, :], dim=-2)
-    T = torch.cat([torch.zeros_like(T[..., :1, :]), T], dim=-2)
+    T = torch.cat([torch.zeros((*T.shape[:1], 1, 1), dtype=T.dtype), T], dim=-2)      # render.py:72-78
     T = torch.exp(-T)
     weights = alphas * T
     rgb = (weights * raw_rgb).sum(-2)
