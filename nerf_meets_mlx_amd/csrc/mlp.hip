@@ -50,14 +50,17 @@ constexpr int F_L0 = 0, F_L1 = 32, F_L5 = 544, F_L6 = 704, F_L7 = 832, F_FA = 96
 constexpr int F_TOTAL = 1184;
 // backward (transposed) weight stream
 constexpr int B_RGB = 0, B_DIR = 4, B_FA = 68, B_L7 = 204, B_L6 = 332, B_L5 = 460, B_L4 = 588;
-constexpr int B_TOTAL = 1100;
+constexpr int B_TOTAL = 1100, B_PADDED = 1120;    // padded with zero fragments to whole 32-fragment ring chunks
 // fp32 bias slots
 constexpr int BI_FEAT = 2048, BI_ALPHA = 2304, BI_DIR = 2336, BI_RGB = 2464, BI_TOTAL = 2496;
-constexpr int64_t PACKED_BYTES = (int64_t)(F_TOTAL + B_TOTAL) * 1024 + BI_TOTAL * 4;
+constexpr int64_t PACKED_BYTES = (int64_t)(F_TOTAL + B_PADDED) * 1024 + BI_TOTAL * 4;
 
 // activation store: fragment slots per 32-sample tile
 constexpr int A_PE = 0, A_DPE = 4, A_H0 = 6;       // H_l at A_H0 + 16 l, l = 0..7
-constexpr int A_FEAT = 134, A_HD = 150, A_SLOTS = 158;
+constexpr int A_FEAT = 134, A_HD = 150;
+// ReLU sign bits of H0..H7 and HD for the backward chain: one 16-byte word per lane and layer (bit 16 nt + i of
+// lane (r,h) = accumulator register i of n-tile nt), so the chain reads 9 KiB per tile instead of 150 KiB
+constexpr int A_MASK = 158, A_SLOTS = 167;
 // gradient store
 constexpr int Z_L0 = 0;                            // dZ_l at 16 l, l = 0..7
 constexpr int Z_F = 128, Z_A = 144, Z_D = 145, Z_RGB = 153, Z_SLOTS = 154;
@@ -136,14 +139,14 @@ __device__ float bwd_src(const float* __restrict__ p, int f, int r, int h, int j
 __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ p, bf16x8* __restrict__ wf,
                                                    bf16x8* __restrict__ wb, float* __restrict__ bias) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int nf = L::F_TOTAL * 64, nb = L::B_TOTAL * 64;
+  const int nf = L::F_TOTAL * 64, nb = L::B_PADDED * 64;
   if (tid < nf + nb) {
     const bool fw = tid < nf;
     const int t = fw ? tid : tid - nf;
     const int f = t >> 6, lane = t & 63, r = lane & 31, h = lane >> 5;
     bf16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(fw ? fwd_src(p, f, r, h, j) : bwd_src(p, f, r, h, j));
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(fw ? fwd_src(p, f, r, h, j) : (f < L::B_TOTAL ? bwd_src(p, f, r, h, j) : 0.0f));
     (fw ? wf : wb)[t] = v;
   } else if (tid < nf + nb + L::BI_TOTAL) {
     const int s = tid - nf - nb;
@@ -208,13 +211,119 @@ __device__ __forceinline__ bf16x8 row_frag(const float* __restrict__ row, int ks
 }
 
 // ------------------------------------------------------------------------------------------
+// weight sources: where a wave gets the 1 KiB A-operand fragment `f` of the packed stream from
+// ------------------------------------------------------------------------------------------
+// one 1 KiB fragment global -> LDS with no VGPR round trip (lane i lands at lds_addr + 16 i).
+// Inline asm on purpose: hipcc treats the builtin as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front
+// of the next ds_read of the same array, which drains the whole prefetch ring every tile.  Hidden in asm, the
+// DMAs are ordered by OUR counted `s_waitcnt vmcnt(N)` + s_barrier (cdna_hip_programming.md 5.7).  M0 carries
+// the LDS byte address and is restored because the compiler owns it.
+__device__ __forceinline__ void dma_frag(const void* gsrc_lane, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+}
+// same with a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (no 64-bit VGPR address per fragment,
+// which hipcc would otherwise hoist out of persistent loops and spill)
+__device__ __forceinline__ void dma_frag_s(const void* gbase_uniform, unsigned lane_off, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(gbase_uniform), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}
+
+// (1) straight from global memory / L1: no synchronisation between waves (variants 1 and 2)
+struct GlobalW {
+  const bf16x8* __restrict__ wlane;    // stream base + lane
+  const float* __restrict__ bias;
+  __device__ __forceinline__ bf16x8 frag(int f, int) { return wlane[f * 64]; }
+  __device__ __forceinline__ float4 bias4(int slot) { return *reinterpret_cast<const float4*>(bias + slot); }
+};
+
+// (2) LDS ring fed by LDS-DMA and shared by the 8 waves of a workgroup (variant 3).  The stream is consumed
+// strictly in order by every wave; chunk = 32 fragments (32 KiB), 4 stages, 3 chunks in flight.  At a chunk
+// boundary every wave: waits for ITS share of the chunk (counted vmcnt: the 2 younger chunks stay in flight),
+// barrier (everybody's share landed; everybody finished reading the previous chunk), then refills the stage that
+// just became free with the chunk 3 ahead (wrapping to the next pass over the weights).
+constexpr int RING_CHUNK = 32, RING_STAGES = 4, RING_STAGE_BYTES = RING_CHUNK * 1024;
+constexpr int RING_BIAS_OFF = RING_STAGES * RING_STAGE_BYTES;          // fp32 bias slots behind the ring
+constexpr int RING_LDS_BYTES = RING_BIAS_OFF + 2560 * 4;
+
+extern __shared__ __attribute__((aligned(16))) char ring_smem[];
+
+constexpr int RING_GROUP = 4;          // fragments per software-pipeline group (one group in use, one in flight)
+
+template <int NCHUNK, int TOTAL>       // TOTAL = fragments consumed per pass (multiple of RING_GROUP)
+struct RingW {
+  const char* __restrict__ wsrc;       // global stream base (uniform)
+  unsigned lane16;                     // 16 * lane
+  unsigned lds0;                       // LDS byte address of ring_smem (M0 values are absolute)
+  int wv;                              // wave id in the workgroup (uniform)
+  int ring_pos;                        // stage of the chunk the prefetch reads from
+  int woff;                            // ring_pos * STAGE + 16 * lane
+  bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
+
+  __device__ __forceinline__ void issue(int chunk, int stage) {
+    const unsigned dst = lds0 + stage * RING_STAGE_BYTES;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = wv + 8 * k;
+      dma_frag_s(wsrc + ((int64_t)chunk * RING_CHUNK + i) * 1024, lane16, dst + i * 1024);
+    }
+  }
+  __device__ __forceinline__ void boundary(int c, int lane) {
+    ring_pos = (ring_pos + 1) & (RING_STAGES - 1);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1));
+    woff = ring_pos * RING_STAGE_BYTES + 16 * lane;
+  }
+  // fetch the group that starts at fragment fn (fn % RING_GROUP == 0) into nxt; crossing into a new chunk first
+  // runs the ring protocol for it (the previous chunk's last group is already in registers)
+  __device__ __forceinline__ void prefetch(int fn, int lane) {
+    if ((fn % RING_CHUNK) == 0) boundary(fn / RING_CHUNK, lane);
+#pragma unroll
+    for (int i = 0; i < RING_GROUP; ++i)
+      nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % RING_CHUNK) * 1024);
+  }
+  __device__ __forceinline__ void start(int lane) {
+    ring_pos = RING_STAGES - 1;
+    woff = 0;
+#pragma unroll
+    for (int c = 0; c < RING_STAGES - 1; ++c) issue(c, c);
+    prefetch(0, lane);
+  }
+  __device__ __forceinline__ bf16x8 frag(int f, int lane) {
+    if ((f % RING_GROUP) == 0) {
+#pragma unroll
+      for (int i = 0; i < RING_GROUP; ++i) cur[i] = nxt[i];
+      prefetch((f + RING_GROUP) % TOTAL, lane);           // wraps to the next pass over the weights
+      __builtin_amdgcn_sched_barrier(0);                  // keep hipcc from hoisting further groups (spills)
+    }
+    return cur[f % RING_GROUP];
+  }
+  __device__ __forceinline__ float4 bias4(int slot) {
+    return *reinterpret_cast<const float4*>(ring_smem + RING_BIAS_OFF + slot * 4);
+  }
+  __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+template <class WS> struct is_ring { static constexpr bool value = false; };
+template <int N, int T> struct is_ring<RingW<N, T>> { static constexpr bool value = true; };
+
+template <class WS>
+__device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }
+
+// ------------------------------------------------------------------------------------------
 // one linear layer on register-resident activations
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void acc_init_bias(f32x16& acc, const float* __restrict__ bias_tile, int h) {
+template <class WS>
+__device__ __forceinline__ void acc_init_bias(f32x16& acc, WS& ws, int slot_tile, int h) {
   // register i <-> row (i&3) + 8 (i>>2) + 4 h : four float4 at rows 8g + 4h
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const float4 b = *reinterpret_cast<const float4*>(bias_tile + 8 * g + 4 * h);
+    const float4 b = ws.bias4(slot_tile + 8 * g + 4 * h);
     acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
   }
 }
@@ -229,37 +338,53 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& acc, bf16x8& lo, bf16
   }
 }
 
-// out[t][2 nt + s] = act( W[nt-tile] . in[t] + bias )     weights: wlane = stream base + lane
-template <int ST, int KS, int NT, bool RELU>
-__device__ __forceinline__ void layer_fwd(const bf16x8* __restrict__ wlane, const float* __restrict__ bias,
-                                          const bf16x8 (&in)[ST][KS], bf16x8 (&out)[ST][2 * NT], int h) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// sign bits of one accumulator tile into the lane's 128-bit layer mask (bit 16 nt + i)
+__device__ __forceinline__ void mask_bits(const f32x16& acc, int nt, u32x4& m) {
+  unsigned w = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w |= (acc[i] > 0.0f) ? (1u << i) : 0u;
+  m[nt >> 1] |= w << (16 * (nt & 1));
+}
+
+// out[t][2 nt + s] = act( W[nt-tile] . in[t] + bias );  fragments FBASE + nt*KS + ks of the stream
+template <int ST, int KS, int NT, bool RELU, bool MASKOUT, class WS>
+__device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, const bf16x8 (&in)[ST][KS],
+                                          bf16x8 (&out)[ST][2 * NT], u32x4 (&mask)[ST], int lane) {
+  const int h = lane >> 5;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     f32x16 acc[ST];
-    acc_init_bias(acc[0], bias + 32 * nt, h);
+    acc_init_bias(acc[0], ws, bias_slot + 32 * nt, h);
 #pragma unroll
     for (int t = 1; t < ST; ++t) acc[t] = acc[0];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a = wlane[(nt * KS + ks) * 64];
+      const bf16x8 a = next_frag(ws, fbase + nt * KS + ks, lane);
 #pragma unroll
       for (int t = 0; t < ST; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in[t][ks], acc[t], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < ST; ++t) acc_to_frags<RELU>(acc[t], out[t][2 * nt], out[t][2 * nt + 1]);
+    for (int t = 0; t < ST; ++t) {
+      acc_to_frags<RELU>(acc[t], out[t][2 * nt], out[t][2 * nt + 1]);
+      if (MASKOUT) mask_bits(acc[t], nt, mask[t]);
+    }
   }
 }
 
-// fragment block address: tile T, slot s, lane (r,h) at byte 32 r + 16 h
-__device__ __forceinline__ bf16x8* frag_ptr(void* base, int64_t tile, int slots, int slot, int r, int h) {
-  return reinterpret_cast<bf16x8*>(base) + ((tile * slots + slot) * 64 + 2 * r + h);
+// fragment block address: tile T, slot s, lane (r,h) at byte 32 r + 16 h.  Written as (uniform 64-bit tile base) +
+// (constant slot offset) + (32-bit lane offset) so that hipcc keeps the base in SGPRs.
+__device__ __forceinline__ bf16x8* frag_ptr(void* base, int64_t tile, int64_t stride16, int slot, int r, int h) {
+  char* tb = reinterpret_cast<char*>(base) + tile * stride16 * 16;
+  return reinterpret_cast<bf16x8*>(tb + slot * 1024 + (unsigned)(32 * r + 16 * h));
 }
 
 template <int COUNT>
-__device__ __forceinline__ void store_frags(void* base, int64_t tile, int slots, int slot0, const bf16x8 (&frags)[COUNT],
-                                            int r, int h) {
+__device__ __forceinline__ void store_frags(void* base, int64_t tile, int64_t stride16, int slot0,
+                                            const bf16x8 (&frags)[COUNT], int r, int h) {
 #pragma unroll
-  for (int k = 0; k < COUNT; ++k) *frag_ptr(base, tile, slots, slot0 + k, r, h) = frags[k];
+  for (int k = 0; k < COUNT; ++k) *frag_ptr(base, tile, stride16, slot0 + k, r, h) = frags[k];
 }
 
 struct FwdArgs {
@@ -273,25 +398,20 @@ struct FwdArgs {
   PeFreq fr;
   float* out;            // [M,4]
   void* acts;            // training store or nullptr
+  int64_t astride;       // 16-byte units between sample tiles of the activation store
 };
 
+// All 12 layers for ST sample tiles of this wave (tile0 .. tile0+ST-1).  Tiles >= ntiles are computed on clamped
+// inputs and never stored, so every wave runs the same instruction stream (the ring needs that).
 // MODE 0: embedded rows;  MODE 1: rays + z with fused positional encodings
-template <int ST, int MODE, bool STORE>
-__global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+template <int ST, int MODE, bool STORE, class WS>
+__device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * ST;
-  const int64_t ntiles = (a.M + 31) >> 5;
-  if (tile0 >= ntiles) return;
-  const bf16x8* __restrict__ w = a.wf + lane;
-
   bf16x8 pe[ST][4], dpe[ST][2];
-  int64_t m_idx[ST];
 #pragma unroll
   for (int t = 0; t < ST; ++t) {
-    int64_t tile = tile0 + t; if (tile >= ntiles) tile = ntiles - 1;       // duplicate work, never stored
+    int64_t tile = tile0 + t; if (tile >= ntiles) tile = ntiles - 1;
     int64_t m = tile * 32 + r; if (m >= a.M) m = a.M - 1;
-    m_idx[t] = m;
     if (MODE == 0) {
       const float* row = a.x + m * 90;
 #pragma unroll
@@ -311,25 +431,39 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs
     }
   }
 #define store(slot0, t, frags, count) \
-  do { if (STORE && tile0 + (t) < ntiles) store_frags<count>(a.acts, tile0 + (t), L::A_SLOTS, slot0, frags, r, h); } while (0)
+  do { if (STORE && tile0 + (t) < ntiles) store_frags<count>(a.acts, tile0 + (t), a.astride, slot0, frags, r, h); } while (0)
 #pragma unroll
   for (int t = 0; t < ST; ++t) { store(L::A_PE, t, pe[t], 4); store(L::A_DPE, t, dpe[t], 2); }
 
   bf16x8 ha[ST][16], hb[ST][16];
-  layer_fwd<ST, 4, 8, true>(w + L::F_L0 * 64, a.bias + 0, pe, ha, h);
+  u32x4 mk[ST];
+#define MASK_BEGIN() do { _Pragma("unroll") for (int t = 0; t < ST; ++t) mk[t] = u32x4{0u, 0u, 0u, 0u}; } while (0)
+#define MASK_STORE(layer) do { if (STORE) { _Pragma("unroll") for (int t = 0; t < ST; ++t) if (tile0 + t < ntiles) \
+    *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0 + t, a.astride, L::A_MASK + (layer), r, h)) = mk[t]; } } while (0)
+  MASK_BEGIN();
+  layer_fwd<ST, 4, 8, true, STORE>(ws, L::F_L0, 0, pe, ha, mk, lane);
+  MASK_STORE(0);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0, t, ha[t], 16);
   // pos1..pos4 (ping-pong)
-  layer_fwd<ST, 16, 8, true>(w + (L::F_L1 + 0 * 128) * 64, a.bias + 256, ha, hb, h);
+  MASK_BEGIN();
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 0 * 128, 256, ha, hb, mk, lane);
+  MASK_STORE(1);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0 + 16, t, hb[t], 16);
-  layer_fwd<ST, 16, 8, true>(w + (L::F_L1 + 1 * 128) * 64, a.bias + 512, hb, ha, h);
+  MASK_BEGIN();
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 1 * 128, 512, hb, ha, mk, lane);
+  MASK_STORE(2);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0 + 32, t, ha[t], 16);
-  layer_fwd<ST, 16, 8, true>(w + (L::F_L1 + 2 * 128) * 64, a.bias + 768, ha, hb, h);
+  MASK_BEGIN();
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 2 * 128, 768, ha, hb, mk, lane);
+  MASK_STORE(3);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0 + 48, t, hb[t], 16);
-  layer_fwd<ST, 16, 8, true>(w + (L::F_L1 + 3 * 128) * 64, a.bias + 1024, hb, ha, h);
+  MASK_BEGIN();
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 3 * 128, 1024, hb, ha, mk, lane);
+  MASK_STORE(4);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0 + 64, t, ha[t], 16);
   // pos5 on concat[input_pos, h]  (models/NeRF.py:224-225)
@@ -337,34 +471,45 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs
     bf16x8 cat[ST][20];
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
+      if (STORE && is_ring<WS>::value) {   // register relief in the training ring kernel: the encoding was just stored
+        const int64_t tl = tile0 + t < ntiles ? tile0 + t : ntiles - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pe[t][k] = *frag_ptr(a.acts, tl, a.astride, L::A_PE + k, r, h);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) cat[t][k] = pe[t][k];
 #pragma unroll
       for (int k = 0; k < 16; ++k) cat[t][4 + k] = ha[t][k];
     }
-    layer_fwd<ST, 20, 8, true>(w + L::F_L5 * 64, a.bias + 1280, cat, hb, h);
+    MASK_BEGIN();
+    layer_fwd<ST, 20, 8, true, STORE>(ws, L::F_L5, 1280, cat, hb, mk, lane);
+    MASK_STORE(5);
   }
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0 + 80, t, hb[t], 16);
-  layer_fwd<ST, 16, 8, true>(w + L::F_L6 * 64, a.bias + 1536, hb, ha, h);
+  MASK_BEGIN();
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L6, 1536, hb, ha, mk, lane);
+  MASK_STORE(6);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0 + 96, t, ha[t], 16);
-  layer_fwd<ST, 16, 8, true>(w + L::F_L7 * 64, a.bias + 1792, ha, hb, h);
+  MASK_BEGIN();
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L7, 1792, ha, hb, mk, lane);
+  MASK_STORE(7);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_H0 + 112, t, hb[t], 16);
   // feature (no activation) and alpha (row 0 of a ninth tile)   models/NeRF.py:229-231
-  layer_fwd<ST, 16, 8, false>(w + L::F_FA * 64, a.bias + L::BI_FEAT, hb, ha, h);
+  layer_fwd<ST, 16, 8, false, false>(ws, L::F_FA, L::BI_FEAT, hb, ha, mk, lane);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_FEAT, t, ha[t], 16);
   float alpha[ST];
   {
     f32x16 acc[ST];
-    acc_init_bias(acc[0], a.bias + L::BI_ALPHA, h);
+    acc_init_bias(acc[0], ws, L::BI_ALPHA, h);
 #pragma unroll
     for (int t = 1; t < ST; ++t) acc[t] = acc[0];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const bf16x8 wa = w[(L::F_FA + 128 + ks) * 64];
+      const bf16x8 wa = next_frag(ws, L::F_FA + 128 + ks, lane);
 #pragma unroll
       for (int t = 0; t < ST; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hb[t][ks], acc[t], 0, 0, 0);
     }
@@ -379,20 +524,27 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs
     for (int t = 0; t < ST; ++t) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) cat[t][k] = ha[t][k];
+      if (STORE && is_ring<WS>::value) {
+        const int64_t tl = tile0 + t < ntiles ? tile0 + t : ntiles - 1;
+        dpe[t][0] = *frag_ptr(a.acts, tl, a.astride, L::A_DPE, r, h);
+        dpe[t][1] = *frag_ptr(a.acts, tl, a.astride, L::A_DPE + 1, r, h);
+      }
       cat[t][16] = dpe[t][0]; cat[t][17] = dpe[t][1];
     }
-    layer_fwd<ST, 18, 4, true>(w + L::F_DIR * 64, a.bias + L::BI_DIR, cat, hd, h);
+    MASK_BEGIN();
+    layer_fwd<ST, 18, 4, true, STORE>(ws, L::F_DIR, L::BI_DIR, cat, hd, mk, lane);
+    MASK_STORE(8);
   }
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::A_HD, t, hd[t], 8);
   {
     f32x16 acc[ST];
-    acc_init_bias(acc[0], a.bias + L::BI_RGB, h);
+    acc_init_bias(acc[0], ws, L::BI_RGB, h);
 #pragma unroll
     for (int t = 1; t < ST; ++t) acc[t] = acc[0];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 wr = w[(L::F_RGB + ks) * 64];
+      const bf16x8 wr = next_frag(ws, L::F_RGB + ks, lane);
 #pragma unroll
       for (int t = 0; t < ST; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr, hd[t][ks], acc[t], 0, 0, 0);
     }
@@ -405,18 +557,59 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs
       }
     }
   }
-  (void)m_idx;
 #undef store
+#undef MASK_BEGIN
+#undef MASK_STORE
+}
+
+// variants 1 / 2: 4 independent waves per workgroup, weights through L1
+template <int ST, int MODE, bool STORE>
+__global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * ST;
+  const int64_t ntiles = (a.M + 31) >> 5;
+  if (tile0 >= ntiles) return;
+  GlobalW ws{a.wf + lane, a.bias};
+  fwd_tiles<ST, MODE, STORE>(a, ws, tile0, ntiles, lane);
+}
+
+__device__ __forceinline__ void ring_load_bias(const float* __restrict__ bias, int count) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x)
+    *reinterpret_cast<float*>(ring_smem + RING_BIAS_OFF + 4 * i) = bias[i];
+}
+
+// variant 3: persistent workgroups of 8 waves x 32 samples, weights through the shared LDS ring
+constexpr int F_CHUNKS = L::F_TOTAL / RING_CHUNK;     // 37
+static_assert(F_CHUNKS * RING_CHUNK == L::F_TOTAL, "forward stream must be whole chunks");
+template <int MODE, bool STORE>
+__global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ntiles = (a.M + 31) >> 5;
+  const int64_t nsuper = (ntiles + 7) >> 3;
+  RingW<F_CHUNKS, L::F_TOTAL> ws;
+  ws.wsrc = reinterpret_cast<const char*>(a.wf);
+  ws.lane16 = 16 * lane;
+  ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
+  ws.wv = wv;
+  ws.start(lane);
+  ring_load_bias(a.bias, L::BI_TOTAL);
+  __syncthreads();
+  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
+    fwd_tiles<1, MODE, STORE>(a, ws, sp * 8 + wv, ntiles, ln);
+  }
+  ws.drain();                                           // the ring always runs 3 chunks ahead
 }
 
 // ------------------------------------------------------------------------------------------
 // backward chain: dZ_l for every layer (stored as fragment blocks for the dW kernel)
 // ------------------------------------------------------------------------------------------
-// out[t][2 kt + s] = mask( W^T[kt-tile] . in[t] )
-template <int ST, int NS, int KT, bool MASK>
-__device__ __forceinline__ void layer_bwd(const bf16x8* __restrict__ wlane, const bf16x8 (&in)[ST][NS],
-                                          bf16x8 (&out)[ST][2 * KT], const void* acts, const int64_t (&tile)[ST],
-                                          int mask_slot, int r, int h) {
+// out[t][2 kt + s] = mask( W^T[kt-tile] . in[t] );  mask = ReLU sign bits written by the forward kernel
+template <int ST, int NS, int KT, bool MASK, class WS>
+__device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&in)[ST][NS], bf16x8 (&out)[ST][2 * KT],
+                                          const u32x4 (&mask)[ST], int lane) {
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     f32x16 acc[ST];
@@ -426,19 +619,18 @@ __device__ __forceinline__ void layer_bwd(const bf16x8* __restrict__ wlane, cons
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      const bf16x8 a = wlane[(kt * NS + ns) * 64];
+      const bf16x8 a = next_frag(ws, fbase + kt * NS + ns, lane);
 #pragma unroll
       for (int t = 0; t < ST; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in[t][ns], acc[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
-      if (MASK) {   // ReLU': the stored activation fragment has the accumulator's (register, lane) layout
-        const bf16x8 m0 = *frag_ptr(const_cast<void*>(acts), tile[t], L::A_SLOTS, mask_slot + 2 * kt, r, h);
-        const bf16x8 m1 = *frag_ptr(const_cast<void*>(acts), tile[t], L::A_SLOTS, mask_slot + 2 * kt + 1, r, h);
+      if (MASK) {
+        const unsigned w = mask[t][kt >> 1] >> (16 * (kt & 1));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          out[t][2 * kt][j] = (__bf16)((float)m0[j] > 0.0f ? acc[t][j] : 0.0f);
-          out[t][2 * kt + 1][j] = (__bf16)((float)m1[j] > 0.0f ? acc[t][8 + j] : 0.0f);
+          out[t][2 * kt][j] = (__bf16)(((w >> j) & 1u) ? acc[t][j] : 0.0f);
+          out[t][2 * kt + 1][j] = (__bf16)(((w >> (8 + j)) & 1u) ? acc[t][8 + j] : 0.0f);
         }
       } else {
         acc_to_frags<false>(acc[t], out[t][2 * kt], out[t][2 * kt + 1]);
@@ -453,16 +645,12 @@ struct BwdArgs {
   const float* d_raw;    // [M,4]
   int64_t M;
   void* dz;
+  int64_t astride, zstride;
 };
 
-template <int ST>
-__global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_bwd_kernel(BwdArgs a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+template <int ST, class WS>
+__device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * ST;
-  const int64_t ntiles = (a.M + 31) >> 5;
-  if (tile0 >= ntiles) return;
-  const bf16x8* __restrict__ w = a.wb + lane;
   int64_t tile[ST];
   bool live[ST];
   bf16x8 zrgb[ST][1], zal[ST][1];
@@ -476,19 +664,26 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_bwd_kernel(BwdArgs
 #pragma unroll
     for (int j = 0; j < 8; ++j) { zrgb[t][0][j] = (__bf16)0.0f; zal[t][0][j] = (__bf16)0.0f; }
     zrgb[t][0][0] = (__bf16)g.x; zrgb[t][0][1] = (__bf16)g.y; zrgb[t][0][2] = (__bf16)g.z;   // rows 0..2 (h == 0)
-    zal[t][0][0] = (__bf16)g.w;                                                               // row 0
+    zal[t][0][0] = (__bf16)g.w;                                                              // row 0
   }
+  // every ReLU mask of the pass is fetched here, so the chain itself issues no loads the compiler must wait for
+  u32x4 mk[9][ST];
+#pragma unroll
+  for (int l = 0; l < 9; ++l)
+#pragma unroll
+    for (int t = 0; t < ST; ++t)
+      mk[l][t] = *reinterpret_cast<const u32x4*>(frag_ptr(const_cast<void*>(a.acts), tile[t], a.astride, L::A_MASK + l, r, h));
 #define store(slot0, t, frags, count) \
-  do { if (live[t]) store_frags<count>(a.dz, tile[t], L::Z_SLOTS, slot0, frags, r, h); } while (0)
+  do { if (live[t]) store_frags<count>(a.dz, tile[t], a.zstride, slot0, frags, r, h); } while (0)
 #pragma unroll
   for (int t = 0; t < ST; ++t) { store(L::Z_RGB, t, zrgb[t], 1); store(L::Z_A, t, zal[t], 1); }
 
   bf16x8 zd[ST][8];
-  layer_bwd<ST, 1, 4, true>(w + L::B_RGB * 64, zrgb, zd, a.acts, tile, L::A_HD, r, h);
+  layer_bwd<ST, 1, 4, true>(ws, L::B_RGB, zrgb, zd, mk[8], lane);
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_D, t, zd[t], 8);
   bf16x8 za[ST][16], zb[ST][16];
-  layer_bwd<ST, 8, 8, false>(w + L::B_DIR * 64, zd, za, a.acts, tile, 0, r, h);            // d feature
+  layer_bwd<ST, 8, 8, false>(ws, L::B_DIR, zd, za, mk[8], lane);            // d feature
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_F, t, za[t], 16);
   {
@@ -499,31 +694,65 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_bwd_kernel(BwdArgs
       for (int k = 0; k < 16; ++k) cat[t][k] = za[t][k];
       cat[t][16] = zal[t][0];
     }
-    layer_bwd<ST, 17, 8, true>(w + L::B_FA * 64, cat, zb, a.acts, tile, L::A_H0 + 112, r, h);   // dZ7
+    layer_bwd<ST, 17, 8, true>(ws, L::B_FA, cat, zb, mk[7], lane);   // dZ7
   }
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 112, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(w + L::B_L7 * 64, zb, za, a.acts, tile, L::A_H0 + 96, r, h);       // dZ6
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L7, zb, za, mk[6], lane);       // dZ6
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 96, t, za[t], 16);
-  layer_bwd<ST, 16, 8, true>(w + L::B_L6 * 64, za, zb, a.acts, tile, L::A_H0 + 80, r, h);       // dZ5
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L6, za, zb, mk[5], lane);       // dZ5
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 80, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(w + L::B_L5 * 64, zb, za, a.acts, tile, L::A_H0 + 64, r, h);       // dZ4
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L5, zb, za, mk[4], lane);       // dZ4
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 64, t, za[t], 16);
-  layer_bwd<ST, 16, 8, true>(w + (L::B_L4 + 0 * 128) * 64, za, zb, a.acts, tile, L::A_H0 + 48, r, h);   // dZ3
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 0 * 128, za, zb, mk[3], lane);   // dZ3
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 48, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(w + (L::B_L4 + 1 * 128) * 64, zb, za, a.acts, tile, L::A_H0 + 32, r, h);   // dZ2
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 1 * 128, zb, za, mk[2], lane);   // dZ2
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 32, t, za[t], 16);
-  layer_bwd<ST, 16, 8, true>(w + (L::B_L4 + 2 * 128) * 64, za, zb, a.acts, tile, L::A_H0 + 16, r, h);   // dZ1
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 2 * 128, za, zb, mk[1], lane);   // dZ1
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 16, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(w + (L::B_L4 + 3 * 128) * 64, zb, za, a.acts, tile, L::A_H0 + 0, r, h);    // dZ0
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 3 * 128, zb, za, mk[0], lane);    // dZ0
 #pragma unroll
   for (int t = 0; t < ST; ++t) store(L::Z_L0 + 0, t, za[t], 16);
+#undef store
+}
+
+template <int ST>
+__global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_bwd_kernel(BwdArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wv) * ST;
+  const int64_t ntiles = (a.M + 31) >> 5;
+  if (tile0 >= ntiles) return;
+  GlobalW ws{a.wb + lane, nullptr};
+  bwd_tiles<ST>(a, ws, tile0, ntiles, lane);
+}
+
+// the transposed stream is padded with zero fragments to whole chunks (1100 -> 1120)
+constexpr int B_CHUNKS = (L::B_TOTAL + RING_CHUNK - 1) / RING_CHUNK;     // 35
+__global__ void __launch_bounds__(512, 2) mlp_bwd_ring_kernel(BwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ntiles = (a.M + 31) >> 5;
+  const int64_t nsuper = (ntiles + 7) >> 3;
+  RingW<B_CHUNKS, L::B_TOTAL> ws;
+  ws.wsrc = reinterpret_cast<const char*>(a.wb);
+  ws.lane16 = 16 * lane;
+  ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
+  ws.wv = wv;
+  ws.start(lane);
+  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    bwd_tiles<1>(a, ws, sp * 8 + wv, ntiles, ln);
+    // the pass ends inside the last chunk (1100 = 34 * 32 + 12): nothing else to do, the next pass starts at a
+    // chunk boundary again because fragment indices restart at 0
+  }
+  ws.drain();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -541,13 +770,16 @@ struct DwArgs {
   DwJob jobs[DW_MAX_JOBS];
   int splits[DW_MAX_JOBS];  // workgroups per job; block b works on job j, split b - prefix(j)
   int ntiles;
+  int64_t astride, zstride;
   const void* acts;
   const void* dz;
   float* grads;
 };
 
 constexpr int DW_FRAG_STRIDE = 1152;                 // 1 KiB + 128 B: neighbouring fragments hit disjoint banks
-constexpr int DW_BUF_BYTES = 32 * DW_FRAG_STRIDE;    // 16 dZ + 16 act fragments
+constexpr int DW_STAGE_BYTES = 32 * DW_FRAG_STRIDE;  // 16 dZ + 16 act fragments per 32-sample tile
+constexpr int DW_STAGES = 4;                         // LDS-DMA ring: 3 tiles in flight behind the one being consumed
+constexpr int DW_LDS_BYTES = DW_STAGES * DW_STAGE_BYTES + 1024;   // + 1 KiB sink for padding DMAs
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds_frag, int u, int hq, int i16) {
   // A/B operand of v_mfma_f32_32x32x16_bf16 with K = samples 16u + 8hq + (0..7) and row/col = feature (natural
@@ -562,16 +794,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_frag, int u, int hq, i
 }
 
 __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* smem = ring_smem;                             // the one dynamic-LDS array of this file
   int bj = blockIdx.x, job_id = 0;
   while (bj >= a.splits[job_id]) { bj -= a.splits[job_id]; ++job_id; }
   const DwJob jb = a.jobs[job_id];
   const int tile_lo = (int)((int64_t)a.ntiles * bj / a.splits[job_id]);
   const int tile_hi = (int)((int64_t)a.ntiles * (bj + 1) / a.splits[job_id]);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wv >> 2, wc = wv & 3;
   const int n_tiles = (jb.nf + 1) >> 1, k_tiles = (jb.kf + 1) >> 1;
-  const int nf_pad = n_tiles * 2, kf_pad = k_tiles * 2;
+  const int nf_pad = n_tiles * 2;
+  const int nfk = jb.nf + jb.kf;                        // real fragments per sample tile (<= 32)
   // this wave's output tiles: n-tiles wr*4 + (0..3), k-tiles wc*2 + (0..1)
   const bool active = (wr * 4 < n_tiles) && (wc * 2 < k_tiles);
   f32x16 acc[4][2];
@@ -583,22 +817,45 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][k][e] = 0.0f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const int g16 = lane >> 4, i16 = lane & 15, hq = g16 >> 1, fsel = g16 & 1;
-  const bf16x8* dzp = reinterpret_cast<const bf16x8*>(a.dz);
-  const bf16x8* acp = reinterpret_cast<const bf16x8*>(a.acts);
-  const int chunks = (nf_pad + kf_pad) * 64;           // 16-byte chunks per sample tile
+  const bf16x8* dzp = reinterpret_cast<const bf16x8*>(a.dz) + lane;
+  const bf16x8* acp = reinterpret_cast<const bf16x8*>(a.acts) + lane;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  const unsigned sink = lds0 + DW_STAGES * DW_STAGE_BYTES;
+
+  // odd fragment counts (rgb / alpha jobs: nf = 1): the partner fragment of the tile is never written by DMA
+  if (jb.nf & 1) {
+    for (int c = tid; c < DW_STAGES * 64; c += 512) {
+      bf16x8 zv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) zv[j] = (__bf16)0.0f;
+      *reinterpret_cast<bf16x8*>(smem + (c >> 6) * DW_STAGE_BYTES + jb.nf * DW_FRAG_STRIDE + (c & 63) * 16) = zv;
+    }
+  }
+  // every wave issues exactly 4 DMAs per tile so that vmcnt arithmetic is uniform: fragment ids wv, wv+8, wv+16, wv+24
+  auto issue = [&](int tile, int stage) {
+    const unsigned st = lds0 + __builtin_amdgcn_readfirstlane(stage) * DW_STAGE_BYTES;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = wv + 8 * k;
+      if (i < jb.nf) dma_frag(dzp + (int64_t)tile * a.zstride + (jb.dz_slot + i) * 64, st + i * DW_FRAG_STRIDE);
+      else if (i < nfk) dma_frag(acp + (int64_t)tile * a.astride + (jb.act_slot + (i - jb.nf)) * 64,
+                                 st + (nf_pad + i - jb.nf) * DW_FRAG_STRIDE);
+      else dma_frag(dzp + (int64_t)tile * a.zstride + jb.dz_slot * 64, sink);      // padding: L2 hit, result unused
+    }
+  };
+  __syncthreads();                                      // zero fill visible before any stage is consumed
+#pragma unroll
+  for (int s_ = 0; s_ < DW_STAGES - 1; ++s_)
+    if (tile_lo + s_ < tile_hi) issue(tile_lo + s_, s_);
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    __syncthreads();                                   // previous tile's reads are done
-    for (int c = tid; c < chunks; c += 512) {
-      const int f = c >> 6, l = c & 63;
-      bf16x8 v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.0f;
-      if (f < nf_pad) { if (f < jb.nf) v = dzp[((int64_t)tile * L::Z_SLOTS + jb.dz_slot + f) * 64 + l]; }
-      else { const int g = f - nf_pad; if (g < jb.kf) v = acp[((int64_t)tile * L::A_SLOTS + jb.act_slot + g) * 64 + l]; }
-      *reinterpret_cast<bf16x8*>(smem + f * DW_FRAG_STRIDE + l * 16) = v;
-    }
-    __syncthreads();
+    const int rem = tile_hi - 1 - tile;                 // tiles issued after this one and still in flight (<= 2)
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // tile landed for every wave; stage (tile-1)%4 is free
+    if (tile + DW_STAGES - 1 < tile_hi) issue(tile + DW_STAGES - 1, (tile - tile_lo + DW_STAGES - 1) % DW_STAGES);
+    const char* st = smem + ((tile - tile_lo) % DW_STAGES) * DW_STAGE_BYTES;
     if (active) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -607,13 +864,13 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
         for (int k = 0; k < 2; ++k) {
           const int kt = wc * 2 + k;
           const int f = nf_pad + (kt < k_tiles ? 2 * kt : 0) + fsel;
-          bfr[k] = tr_frag(smem + f * DW_FRAG_STRIDE, u, hq, i16);
+          bfr[k] = tr_frag(st + f * DW_FRAG_STRIDE, u, hq, i16);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int nt = wr * 4 + i;
           const int f = (nt < n_tiles ? 2 * nt : 0) + fsel;
-          const bf16x8 afr = tr_frag(smem + f * DW_FRAG_STRIDE, u, hq, i16);
+          const bf16x8 afr = tr_frag(st + f * DW_FRAG_STRIDE, u, hq, i16);
           if (wc == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bsum[i] += (float)afr[j];
@@ -650,7 +907,17 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
   }
 }
 
-static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 (2 waves/SIMD), 2: ST=2 (1 wave/SIMD)
+static int g_dw_wgs = 768;
+static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
+static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
+static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad16; }
+static int g_mlp_variant = 0;   // 0: auto (= 3), 1: ST=1 via L1, 2: ST=2 via L1, 3: LDS ring, 8 waves x 32 samples
+static int g_ring_wgs = 256;     // persistent workgroups of the ring kernels (one per CU)
+
+template <class K>
+static void ensure_lds(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 static bool arch_ok(const nerf_mlp_arch* a) {
   return a && a->n_layers == 8 && a->width == 256 && a->in_pos == 63 && a->in_dir == 27 && a->skip_layer == 4 &&
@@ -664,16 +931,19 @@ using namespace nerf;
 extern "C" int nerf_set_option(const char* key, int value) {
   NERF_REQUIRE(key, NERF_E_NULL, "nerf_set_option: key is NULL");
   if (!strcmp(key, "mlp_variant")) { g_mlp_variant = value; return NERF_OK; }
+  if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 256; return NERF_OK; }
+  if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
+  if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 256; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
 extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) { return arch_ok(arch) ? L::P_TOTAL : -1; }
 extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) { return arch_ok(arch) ? L::PACKED_BYTES : -1; }
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
-  return arch_ok(arch) && M >= 0 ? ((M + 31) / 32) * (int64_t)L::A_SLOTS * 1024 : -1;
+  return arch_ok(arch) && M >= 0 ? ((M + 31) / 32) * astride16() * 16 : -1;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
-  return arch_ok(arch) && M >= 0 ? ((M + 31) / 32) * (int64_t)L::Z_SLOTS * 1024 : -1;
+  return arch_ok(arch) && M >= 0 ? ((M + 31) / 32) * zstride16() * 16 : -1;
 }
 
 #define NERF_ARCH_CHECK(who) \
@@ -685,8 +955,8 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
   char* base = static_cast<char*>(packed);
   bf16x8* wf = reinterpret_cast<bf16x8*>(base);
   bf16x8* wb = reinterpret_cast<bf16x8*>(base + (size_t)L::F_TOTAL * 1024);
-  float* bias = reinterpret_cast<float*>(base + (size_t)(L::F_TOTAL + L::B_TOTAL) * 1024);
-  const int total = (L::F_TOTAL + L::B_TOTAL) * 64 + L::BI_TOTAL;
+  float* bias = reinterpret_cast<float*>(base + (size_t)(L::F_TOTAL + L::B_PADDED) * 1024);
+  const int total = (L::F_TOTAL + L::B_PADDED) * 64 + L::BI_TOTAL;
   hipLaunchKernelGGL(pack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), params, wf, wb, bias);
   return check_launch("nerf_mlp_pack");
 }
@@ -702,14 +972,24 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   FwdArgs a;
   const char* base = static_cast<const char*>(packed);
   a.wf = reinterpret_cast<const bf16x8*>(base);
-  a.bias = reinterpret_cast<const float*>(base + (size_t)(L::F_TOTAL + L::B_TOTAL) * 1024);
-  a.x = x; a.rays = rays; a.z = z; a.M = M; a.n = n; a.out = out; a.acts = acts;
+  a.bias = reinterpret_cast<const float*>(base + (size_t)(L::F_TOTAL + L::B_PADDED) * 1024);
+  a.x = x; a.rays = rays; a.z = z; a.M = M; a.n = n; a.out = out; a.acts = acts; a.astride = astride16();
   fill_freqs(a.fr, freq_mode);
   const int64_t ntiles = (M + 31) / 32;
-  const int st = g_mlp_variant == 1 ? 1 : 2;
+  auto s = as_stream(stream);
+  const int variant = (g_mlp_variant == 0) ? (MODE == 1 ? 3 : 1) : g_mlp_variant;
+  if (variant == 3 && MODE == 1) {
+    const int64_t nsuper = (ntiles + 7) / 8;
+    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
+    static bool once = false;
+    if (!once) { ensure_lds(mlp_fwd_ring_kernel<1, true>, RING_LDS_BYTES); ensure_lds(mlp_fwd_ring_kernel<1, false>, RING_LDS_BYTES); once = true; }
+    if (acts) hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, true>), g, b, RING_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, false>), g, b, RING_LDS_BYTES, s, a);
+    return check_launch("mlp forward (ring)");
+  }
+  const int st = variant == 2 ? 2 : 1;
   const int64_t blocks = (ntiles + 4 * st - 1) / (4 * st);
   NERF_REQUIRE(blocks < (1ll << 31), NERF_E_SHAPE, "mlp forward: M too large");
-  auto s = as_stream(stream);
   const dim3 g((unsigned)blocks), b(256);
   if (st == 1) {
     if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<1, MODE, true>), g, b, 0, s, a);
@@ -749,11 +1029,20 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   // ---- 1. dZ chain
   BwdArgs b;
   b.wb = reinterpret_cast<const bf16x8*>(static_cast<const char*>(packed) + (size_t)L::F_TOTAL * 1024);
-  b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz;
-  const int st = g_mlp_variant == 1 ? 1 : 2;
-  const int64_t blocks = (ntiles + 4 * st - 1) / (4 * st);
-  if (st == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, b);
-  else hipLaunchKernelGGL((mlp_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+  b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz; b.astride = astride16(); b.zstride = zstride16();
+  const int variant = g_mlp_variant == 0 ? 3 : g_mlp_variant;
+  if (variant == 3) {
+    const int64_t nsuper = (ntiles + 7) / 8;
+    static bool once = false;
+    if (!once) { ensure_lds(mlp_bwd_ring_kernel, RING_LDS_BYTES); once = true; }
+    hipLaunchKernelGGL(mlp_bwd_ring_kernel, dim3((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), dim3(512),
+                       RING_LDS_BYTES, s, b);
+  } else {
+    const int st = variant == 2 ? 2 : 1;
+    const int64_t blocks = (ntiles + 4 * st - 1) / (4 * st);
+    if (st == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, b);
+  }
   int rc = check_launch("mlp backward chain");
   if (rc) return rc;
   // ---- 2. dW / db
@@ -774,17 +1063,19 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   job(L::Z_D, 8, L::A_FEAT, 16, L::P_WD, 283, 0, 128, 256, L::P_BD);                               // dir0 | feature
   job(L::Z_D, 8, L::A_DPE, 2, L::P_WD, 283, 256, 128, 27, -1);                                     // dir0 | dirPE
   job(L::Z_RGB, 1, L::A_HD, 8, L::P_WR, 128, 0, 3, 128, L::P_BR);                                  // rgb
-  // split the sample tiles of every job over workgroups in proportion to its MFMA work
+  // The dW pass is HBM-bound (every dZ / activation byte is read once per job, 128 FLOP/B), so a job's cost is
+  // its bytes per sample tile (nf + kf KiB).  One workgroup per CU (148 KiB LDS each): split the sample range of
+  // every job over ~256 workgroups in proportion to those bytes so that all of them finish together.
   int64_t units[DW_MAX_JOBS], total_units = 0;
   for (int j = 0; j < nj; ++j) {
-    units[j] = (int64_t)((d.jobs[j].nf + 1) / 2) * ((d.jobs[j].kf + 1) / 2);
+    units[j] = d.jobs[j].nf + d.jobs[j].kf;
     total_units += units[j];
   }
-  const int target_wgs = 512;
+  const int target_wgs = g_dw_wgs;
   int nw = 0;
   for (int j = 0; j < DW_MAX_JOBS; ++j) d.splits[j] = 0;
   for (int j = 0; j < nj; ++j) {
-    int64_t splits = (units[j] * target_wgs + total_units - 1) / total_units;
+    int64_t splits = (units[j] * target_wgs + total_units / 2) / total_units;
     const int64_t max_splits = (ntiles + 3) / 4;              // >= 4 sample tiles per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -793,8 +1084,13 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   }
   hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * L::P_TOTAL, s);
   if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
-  d.ntiles = (int)ntiles;
+  d.ntiles = (int)ntiles; d.astride = astride16(); d.zstride = zstride16();
   d.acts = acts; d.dz = dz; d.grads = grads;
-  hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(512), DW_BUF_BYTES, s, d);
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    lds_attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(512), DW_LDS_BYTES, s, d);
   return check_launch("mlp dW");
 }

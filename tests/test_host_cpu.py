@@ -43,8 +43,8 @@ def test_host_argument_validation_without_gpu():
                                       None, None) == -2                      # NERF_E_SHAPE
     arch = _native.MlpArch(8, 256, 63, 27, 4, 1)
     assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844
-    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == (1184 + 1100) * 1024 + 2496 * 4
-    assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 3 * 158 * 1024
+    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == (1184 + 1120) * 1024 + 2496 * 4
+    assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 3 * 167 * 1024
     bad = _native.MlpArch(8, 128, 63, 27, 4, 1)
     assert lib.nerf_mlp_param_count(C.byref(bad)) == -1
     with pytest.raises(ValueError):

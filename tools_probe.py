@@ -18,7 +18,8 @@ def timeit(fn, it=5):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
-for variant in (1, 2):
+variants = [int(a) for a in sys.argv[1:]] or [1, 2, 3]
+for variant in variants:
     _native.check(_native.lib().nerf_set_option(b"mlp_variant", variant))
     for B, n in ((1024, 64), (4096, 64), (4096, 192), (32768, 64), (32768, 192)):
         r = rays(B); z = sampling.sample_coarse(r, n) if n == 64 else torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
