@@ -143,11 +143,17 @@ def cpu_baseline(args):
     """The CPU oracle (op-for-op torch-CPU restatement of the reference path) on a bounded sample
     of the same workload: same train:render ray ratio, small batch, all host cores."""
     from oracle import nerf_oracle as O
-    cores = os.cpu_count() or 1
+    # host share of a 1-GPU box: the scheduler affinity when it is set, never more than 16 threads
+    # (an 8-GPU host exposes 256 logical CPUs to every process; oversubscribing them makes torch-CPU crawl)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     arch = O.NerfArch()
     tr = O.OracleTrainer(arch, 64, 128, seed=0)
-    b_train, b_render, steps = 64, 512, 2
+    b_train, b_render, steps = 32, 256, 2
     g = torch.Generator().manual_seed(0)
     o = torch.nn.functional.normalize(torch.randn(b_render, 3, generator=g), dim=-1) * 4.0
     d = -o / 4.0 + 0.2 * torch.randn(b_render, 3, generator=g)

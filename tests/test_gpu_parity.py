@@ -411,7 +411,7 @@ def test_mlp_backward_matches_autograd(variant, B, n):
                 assert _rel_l2(a, b) < tol and _relmax(a, b) < 4 * tol, (name, part, _rel_l2(a, b), _relmax(a, b))
                 off += cnt
         assert off == 595844
-        assert _rel_l2(grads, want) < 1e-2
+        assert _rel_l2(grads, want) < tol / 2
     finally:
         _native.check(_native.lib().nerf_set_option(b"mlp_variant", 0))
 
