@@ -58,7 +58,9 @@ def main():
 
     H = W = args.hw
     imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, args.train_images, seed=0, device=dev)
-    tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=128, seed=0, device=dev,
+    # seed 4: both networks start with sigma > 0 (a net whose raw sigma starts negative everywhere has an exactly
+    # zero gradient under the reference's formulas and never trains -- DESIGN.md section 8)
+    tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=128, seed=4, device=dev,
                  chunk=args.render_rays)
     # render chunk of this rank: a contiguous slice of a render pose's pixel list, resident on the device
     lo, _ = parallel.shard_range(H * W, rank, world)

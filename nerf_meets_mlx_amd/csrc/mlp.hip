@@ -253,9 +253,9 @@ constexpr int RING_LDS_BYTES = RING_BIAS_OFF + 2560 * 4;
 
 extern __shared__ __attribute__((aligned(16))) char ring_smem[];
 
-constexpr int RING_GROUP = 4;          // fragments per software-pipeline group (one group in use, one in flight)
-
-template <int NCHUNK, int TOTAL>       // TOTAL = fragments consumed per pass (multiple of RING_GROUP)
+// RING_GROUP = fragments per software-pipeline group (one group in use, one in flight); TOTAL = fragments
+// consumed per pass (multiple of RING_GROUP)
+template <int NCHUNK, int TOTAL, int RING_GROUP = 4>
 struct RingW {
   const char* __restrict__ wsrc;       // global stream base (uniform)
   unsigned lane16;                     // 16 * lane
@@ -310,7 +310,7 @@ struct RingW {
 };
 
 template <class WS> struct is_ring { static constexpr bool value = false; };
-template <int N, int T> struct is_ring<RingW<N, T>> { static constexpr bool value = true; };
+template <int N, int T, int G> struct is_ring<RingW<N, T, G>> { static constexpr bool value = true; };
 
 template <class WS>
 __device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }
@@ -431,14 +431,14 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
     }
   }
 #define store(slot0, t, frags, count) \
-  do { if (STORE && tile0 + (t) < ntiles) store_frags<count>(a.acts, tile0 + (t), a.astride, slot0, frags, r, h); } while (0)
+  do { if (STORE) store_frags<count>(a.acts, tile0 + (t), a.astride, slot0, frags, r, h); } while (0)
 #pragma unroll
   for (int t = 0; t < ST; ++t) { store(L::A_PE, t, pe[t], 4); store(L::A_DPE, t, dpe[t], 2); }
 
   bf16x8 ha[ST][16], hb[ST][16];
   u32x4 mk[ST];
 #define MASK_BEGIN() do { _Pragma("unroll") for (int t = 0; t < ST; ++t) mk[t] = u32x4{0u, 0u, 0u, 0u}; } while (0)
-#define MASK_STORE(layer) do { if (STORE) { _Pragma("unroll") for (int t = 0; t < ST; ++t) if (tile0 + t < ntiles) \
+#define MASK_STORE(layer) do { if (STORE) { _Pragma("unroll") for (int t = 0; t < ST; ++t) \
     *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0 + t, a.astride, L::A_MASK + (layer), r, h)) = mk[t]; } } while (0)
   MASK_BEGIN();
   layer_fwd<ST, 4, 8, true, STORE>(ws, L::F_L0, 0, pe, ha, mk, lane);
@@ -472,9 +472,8 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
       if (STORE && is_ring<WS>::value) {   // register relief in the training ring kernel: the encoding was just stored
-        const int64_t tl = tile0 + t < ntiles ? tile0 + t : ntiles - 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pe[t][k] = *frag_ptr(a.acts, tl, a.astride, L::A_PE + k, r, h);
+        for (int k = 0; k < 4; ++k) pe[t][k] = *frag_ptr(a.acts, tile0 + t, a.astride, L::A_PE + k, r, h);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) cat[t][k] = pe[t][k];
@@ -525,9 +524,8 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
 #pragma unroll
       for (int k = 0; k < 16; ++k) cat[t][k] = ha[t][k];
       if (STORE && is_ring<WS>::value) {
-        const int64_t tl = tile0 + t < ntiles ? tile0 + t : ntiles - 1;
-        dpe[t][0] = *frag_ptr(a.acts, tl, a.astride, L::A_DPE, r, h);
-        dpe[t][1] = *frag_ptr(a.acts, tl, a.astride, L::A_DPE + 1, r, h);
+        dpe[t][0] = *frag_ptr(a.acts, tile0 + t, a.astride, L::A_DPE, r, h);
+        dpe[t][1] = *frag_ptr(a.acts, tile0 + t, a.astride, L::A_DPE + 1, r, h);
       }
       cat[t][16] = dpe[t][0]; cat[t][17] = dpe[t][1];
     }
@@ -587,7 +585,7 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ntiles = (a.M + 31) >> 5;
   const int64_t nsuper = (ntiles + 7) >> 3;
-  RingW<F_CHUNKS, L::F_TOTAL> ws;
+  RingW<F_CHUNKS, L::F_TOTAL, (STORE ? 2 : 4)> ws;
   ws.wsrc = reinterpret_cast<const char*>(a.wf);
   ws.lane16 = 16 * lane;
   ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
@@ -674,7 +672,7 @@ __device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile
     for (int t = 0; t < ST; ++t)
       mk[l][t] = *reinterpret_cast<const u32x4*>(frag_ptr(const_cast<void*>(a.acts), tile[t], a.astride, L::A_MASK + l, r, h));
 #define store(slot0, t, frags, count) \
-  do { if (live[t]) store_frags<count>(a.dz, tile[t], a.zstride, slot0, frags, r, h); } while (0)
+  do { store_frags<count>(a.dz, tile0 + (t), a.zstride, slot0, frags, r, h); } while (0)
 #pragma unroll
   for (int t = 0; t < ST; ++t) { store(L::Z_RGB, t, zrgb[t], 1); store(L::Z_A, t, zal[t], 1); }
 
@@ -940,10 +938,10 @@ extern "C" int nerf_set_option(const char* key, int value) {
 extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) { return arch_ok(arch) ? L::P_TOTAL : -1; }
 extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) { return arch_ok(arch) ? L::PACKED_BYTES : -1; }
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
-  return arch_ok(arch) && M >= 0 ? ((M + 31) / 32) * astride16() * 16 : -1;
+  return arch_ok(arch) && M >= 0 ? ((((M + 31) / 32) + 7) / 8 * 8) * astride16() * 16 : -1;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
-  return arch_ok(arch) && M >= 0 ? ((M + 31) / 32) * zstride16() * 16 : -1;
+  return arch_ok(arch) && M >= 0 ? ((((M + 31) / 32) + 7) / 8 * 8) * zstride16() * 16 : -1;
 }
 
 #define NERF_ARCH_CHECK(who) \

@@ -31,12 +31,12 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t B, 
 template <int CH>   // CH = ceil(n/64): consecutive bins handled by one lane in the scan
 __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict__ z, const float* __restrict__ w,
                                                          const float* __restrict__ u, int64_t B, int n, int N,
-                                                         float eps, float* __restrict__ z_new,
+                                                         int P, float eps, float* __restrict__ z_new,
                                                          float* __restrict__ z_merged, float* __restrict__ cdf_out,
                                                          int64_t* __restrict__ inds_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int per_wave = (n + 1) * 2 + ((n + N + 3) & ~3);
+  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3);
   float* s_cdf = smem + wv * per_wave;
   float* s_zmid = s_cdf + (n + 1);
   float* s_all = s_zmid + (n + 1);
@@ -106,17 +106,54 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     if (z_merged) {
-      // stable rank sort of the n+N depths (ties broken by position), NaN last like torch.sort
       const int tot = n + N;
-      for (int i = lane; i < tot; i += WAVE) {
-        const float v = s_all[i];
-        int rank = 0;
-        for (int k = 0; k < tot; ++k) {
-          const float o = s_all[k];
-          const bool less = (o < v) || (v != v && o == o) || ((o == v || (o != o && v != v)) && k < i);
-          rank += less ? 1 : 0;
+      float* s_new = s_all + n;
+      // is the coarse list ascending (it always is on the render path)?  Then: bitonic sort of the N new depths in
+      // LDS + two binary-search rank passes = O((n+N) log) instead of the O((n+N)^2) rank sort below.
+      bool asc = true;
+      for (int i = lane; i + 1 < n; i += WAVE) asc = asc && (s_all[i] <= s_all[i + 1]);
+      if (__all(asc)) {
+        for (int i = N + lane; i < P; i += WAVE) s_new[i] = __builtin_inff();          // pad to a power of two
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 2; k <= P; k <<= 1) {
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int pi = lane; pi < (P >> 1); pi += WAVE) {
+              const int i = ((pi & ~(j - 1)) << 1) | (pi & (j - 1));
+              const int q = i | j;
+              const float a = s_new[i], b = s_new[q];
+              const bool up = (i & k) == 0;
+              if ((a > b) == up) { s_new[i] = b; s_new[q] = a; }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+          }
         }
-        z_merged[ray * tot + rank] = v;
+        // ties: coarse depths first.  rank(z_i) = i + #{new < z_i};  rank(new_j) = j + #{z <= new_j}
+        for (int i = lane; i < n; i += WAVE) {
+          const float v = s_all[i];
+          int lo = 0, hi = N;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_new[mid] < v) lo = mid + 1; else hi = mid; }
+          z_merged[ray * tot + i + lo] = v;
+        }
+        for (int j = lane; j < N; j += WAVE) {
+          const float v = s_new[j];
+          int lo = 0, hi = n;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_all[mid] <= v) lo = mid + 1; else hi = mid; }
+          z_merged[ray * tot + j + lo] = v;
+        }
+      } else {
+        // general input: stable rank sort of the n+N depths (ties broken by position), NaN last like torch.sort
+        for (int i = lane; i < tot; i += WAVE) {
+          const float v = s_all[i];
+          int rank = 0;
+          for (int k = 0; k < tot; ++k) {
+            const float o = s_all[k];
+            const bool less = (o < v) || (v != v && o == o) || ((o == v || (o != o && v != v)) && k < i);
+            rank += less ? 1 : 0;
+          }
+          z_merged[ray * tot + rank] = v;
+        }
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -148,12 +185,14 @@ extern "C" int nerf_importance_sample(const float* z, const float* weights, cons
                "nerf_importance_sample: unsupported n=%d N=%d (2<=n<=256, 1<=N<=512)", n, N);
   if (B <= 0) return NERF_OK;
   NERF_REQUIRE(z && weights && u, NERF_E_NULL, "nerf_importance_sample: z/weights/u is NULL");
-  const int per_wave = (n + 1) * 2 + ((n + N + 3) & ~3);
+  int P = 2;
+  while (P < N) P <<= 1;                                  // bitonic sort width of the new depths
+  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3);
   const size_t lds = (size_t)per_wave * 4 * sizeof(float);
   const int grid = (int)((B + 3) / 4 > 256 * 8 ? 256 * 8 : (B + 3) / 4);
   const int ch = (n + 63) / 64;
   auto st = as_stream(stream);
-#define LAUNCH(C) hipLaunchKernelGGL(importance_kernel<C>, dim3(grid), dim3(256), lds, st, z, weights, u, B, n, N, eps, z_new, z_merged, cdf, inds)
+#define LAUNCH(C) hipLaunchKernelGGL(importance_kernel<C>, dim3(grid), dim3(256), lds, st, z, weights, u, B, n, N, P, eps, z_new, z_merged, cdf, inds)
   if (ch == 1) LAUNCH(1); else if (ch == 2) LAUNCH(2); else if (ch == 3) LAUNCH(3); else LAUNCH(4);
 #undef LAUNCH
   return check_launch("nerf_importance_sample");

@@ -44,7 +44,7 @@ def test_host_argument_validation_without_gpu():
     arch = _native.MlpArch(8, 256, 63, 27, 4, 1)
     assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844
     assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == (1184 + 1120) * 1024 + 2496 * 4
-    assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 3 * 167 * 1024
+    assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
     bad = _native.MlpArch(8, 128, 63, 27, 4, 1)
     assert lib.nerf_mlp_param_count(C.byref(bad)) == -1
     with pytest.raises(ValueError):
