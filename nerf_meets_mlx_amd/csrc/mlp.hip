@@ -328,31 +328,36 @@ __device__ __forceinline__ void acc_init_bias(f32x16& acc, WS& ws, int slot_tile
   }
 }
 
-template <bool RELU>
-__device__ __forceinline__ void acc_to_frags(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float a = acc[j], b = acc[8 + j];
-    lo[j] = (__bf16)(RELU ? fmaxf(a, 0.0f) : a);
-    hi[j] = (__bf16)(RELU ? fmaxf(b, 0.0f) : b);
-  }
-}
-
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// sign bits of one accumulator tile into the lane's 128-bit layer mask (bit 16 nt + i)
-__device__ __forceinline__ void mask_bits(const f32x16& acc, int nt, u32x4& m) {
+// Epilogue of one accumulator tile, in four quarters of 4 registers so that it can be spread between the MFMAs
+// of the NEXT n-tile (the two waves of a SIMD run the same stream in lockstep behind the ring barrier; an epilogue
+// done in one block would leave the matrix pipe idle in both at once).  ReLU is an integer max on the bit pattern:
+// one VALU op, without the canonicalising v_max hipcc puts in front of fmaxf on MFMA results.
+template <bool RELU, bool MASKOUT>
+__device__ __forceinline__ void finish_quarter(const f32x16& acc, int q, int nt, bf16x8& lo, bf16x8& hi, u32x4& mask) {
   unsigned w = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) w |= (acc[i] > 0.0f) ? (1u << i) : 0u;
-  m[nt >> 1] |= w << (16 * (nt & 1));
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * q + e;
+    float v = acc[i];
+    if (MASKOUT) w |= (v > 0.0f) ? (1u << i) : 0u;
+    if (RELU) v = __int_as_float(max(__float_as_int(v), 0));   // ReLU on the bit pattern: one v_max_i32, no canonicalise
+    if (i < 8) lo[i] = (__bf16)v; else hi[i - 8] = (__bf16)v;
+  }
+  if (MASKOUT) mask[nt >> 1] |= w << (16 * (nt & 1));      // bit 16 (nt&1) + i of word nt>>1
 }
 
-// out[t][2 nt + s] = act( W[nt-tile] . in[t] + bias );  fragments FBASE + nt*KS + ks of the stream
+__host__ __device__ constexpr int quarter_pos(int ks_count, int q) {   // k-step after which quarter q is retired
+  return ks_count >= 8 ? (q * ks_count) / 4 + 1 : (q < ks_count ? q : ks_count - 1);
+}
+
+// out[t][2 nt + s] = act( W[nt-tile] . in[t] + bias );  fragments fbase + nt*KS + ks of the stream
 template <int ST, int KS, int NT, bool RELU, bool MASKOUT, class WS>
 __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, const bf16x8 (&in)[ST][KS],
                                           bf16x8 (&out)[ST][2 * NT], u32x4 (&mask)[ST], int lane) {
   const int h = lane >> 5;
+  f32x16 prev[ST];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     f32x16 acc[ST];
@@ -364,13 +369,24 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
       const bf16x8 a = next_frag(ws, fbase + nt * KS + ks, lane);
 #pragma unroll
       for (int t = 0; t < ST; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in[t][ks], acc[t], 0, 0, 0);
+      if (nt > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (quarter_pos(KS, q) == ks) {
+#pragma unroll
+            for (int t = 0; t < ST; ++t)
+              finish_quarter<RELU, MASKOUT>(prev[t], q, nt - 1, out[t][2 * nt - 2], out[t][2 * nt - 1], mask[t]);
+          }
+      }
     }
 #pragma unroll
-    for (int t = 0; t < ST; ++t) {
-      acc_to_frags<RELU>(acc[t], out[t][2 * nt], out[t][2 * nt + 1]);
-      if (MASKOUT) mask_bits(acc[t], nt, mask[t]);
-    }
+    for (int t = 0; t < ST; ++t) prev[t] = acc[t];
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < ST; ++t)
+      finish_quarter<RELU, MASKOUT>(prev[t], q, NT - 1, out[t][2 * NT - 2], out[t][2 * NT - 1], mask[t]);
 }
 
 // fragment block address: tile T, slot s, lane (r,h) at byte 32 r + 16 h.  Written as (uniform 64-bit tile base) +
@@ -604,10 +620,24 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
 // ------------------------------------------------------------------------------------------
 // backward chain: dZ_l for every layer (stored as fragment blocks for the dW kernel)
 // ------------------------------------------------------------------------------------------
+// backward epilogue quarter: ReLU' from the forward's sign bits, then bf16
+template <bool MASK>
+__device__ __forceinline__ void finish_quarter_bwd(const f32x16& acc, int q, int kt, bf16x8& lo, bf16x8& hi,
+                                                   const u32x4& mask) {
+  const unsigned w = MASK ? (mask[kt >> 1] >> (16 * (kt & 1))) : 0xFFFFu;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * q + e;
+    const float v = (!MASK || ((w >> i) & 1u)) ? acc[i] : 0.0f;
+    if (i < 8) lo[i] = (__bf16)v; else hi[i - 8] = (__bf16)v;
+  }
+}
+
 // out[t][2 kt + s] = mask( W^T[kt-tile] . in[t] );  mask = ReLU sign bits written by the forward kernel
 template <int ST, int NS, int KT, bool MASK, class WS>
 __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&in)[ST][NS], bf16x8 (&out)[ST][2 * KT],
                                           const u32x4 (&mask)[ST], int lane) {
+  f32x16 prev[ST];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     f32x16 acc[ST];
@@ -620,21 +650,24 @@ __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&in)[
       const bf16x8 a = next_frag(ws, fbase + kt * NS + ns, lane);
 #pragma unroll
       for (int t = 0; t < ST; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in[t][ns], acc[t], 0, 0, 0);
-    }
+      if (kt > 0) {
 #pragma unroll
-    for (int t = 0; t < ST; ++t) {
-      if (MASK) {
-        const unsigned w = mask[t][kt >> 1] >> (16 * (kt & 1));
+        for (int q = 0; q < 4; ++q)
+          if (quarter_pos(NS, q) == ns) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          out[t][2 * kt][j] = (__bf16)(((w >> j) & 1u) ? acc[t][j] : 0.0f);
-          out[t][2 * kt + 1][j] = (__bf16)(((w >> (8 + j)) & 1u) ? acc[t][8 + j] : 0.0f);
-        }
-      } else {
-        acc_to_frags<false>(acc[t], out[t][2 * kt], out[t][2 * kt + 1]);
+            for (int t = 0; t < ST; ++t)
+              finish_quarter_bwd<MASK>(prev[t], q, kt - 1, out[t][2 * kt - 2], out[t][2 * kt - 1], mask[t]);
+          }
       }
     }
+#pragma unroll
+    for (int t = 0; t < ST; ++t) prev[t] = acc[t];
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < ST; ++t)
+      finish_quarter_bwd<MASK>(prev[t], q, KT - 1, out[t][2 * KT - 2], out[t][2 * KT - 1], mask[t]);
 }
 
 struct BwdArgs {
