@@ -50,7 +50,7 @@ def main():
     from nerf_meets_mlx_amd.engine.trainer import Trainer
     from nerf_meets_mlx_amd.rendering import ray
 
-    rank, world, local = parallel.init_from_env()
+    rank, world, local = parallel.init_from_env(os.environ.get("NERF_DIST_BACKEND"))   # default: nccl (= RCCL) on GPUs
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -120,6 +120,16 @@ def main():
     k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["t"]]))
     flop = FLOP_PER_SAMPLE_FWD * args.render_rays * 192
     achieved = flop / (k_ms * 1e-3) / 1e12
+    # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
+    # this same command, committed under profiles/); null when no measurement matches the workload
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
+            pm = json.load(fp)
+        if pm.get("samples_per_launch") == args.render_rays * 192:
+            traffic = pm["hbm_bytes_per_launch"]
+    except OSError:
+        pass
     line = {
         "metric": "train+render rays/sec on Lego 800x800 (synthetic), coarse+fine 64+128",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -129,9 +139,10 @@ def main():
                                f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU",
                    "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
         "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
-        "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel (render fine pass)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "mlp_fwd_ring_kernel (render fine pass)", "achieved": achieved,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * 192},
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "algorithmic_bytes": args.render_rays * (192 * 20 + 44),
+                     "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * 192},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)

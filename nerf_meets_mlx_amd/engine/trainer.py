@@ -136,6 +136,28 @@ class Trainer:
             sd["fine"] = self.fine.params.cpu()
         return sd
 
+    def save(self, path: str):
+        """Flat-buffer checkpoint as .npz (the reference declares --i_weights / --ft_path but never implements them,
+        `models/NeRF.py:122-125`)."""
+        sd = self.state_dict()
+        arrays = {"it": np.array(sd["it"]), "coarse": sd["coarse"].numpy()}
+        if "fine" in sd:
+            arrays["fine"] = sd["fine"].numpy()
+        for k, (m, v) in sd["adam"].items():
+            arrays[f"adam_{k}_m"], arrays[f"adam_{k}_v"] = m.numpy(), v.numpy()
+        np.savez(path, **arrays)
+
+    def load(self, path: str):
+        z = np.load(path)
+        sd = {"it": int(z["it"]), "coarse": torch.from_numpy(z["coarse"]), "adam": {}}
+        if "fine" in z:
+            sd["fine"] = torch.from_numpy(z["fine"])
+        for k in z.files:
+            if k.startswith("adam_") and k.endswith("_m"):
+                name = k[5:-2]
+                sd["adam"][name] = [torch.from_numpy(z[k]), torch.from_numpy(z[f"adam_{name}_v"])]
+        self.load_state_dict(sd)
+
     def load_state_dict(self, sd):
         self.it = int(sd["it"])
         self.coarse.load_flat(sd["coarse"])

@@ -78,3 +78,32 @@ def test_product_package_never_imports_oracle():
     out = subprocess.run(["grep", "-rIl", "-E", r"^\s*(from|import) +oracle", os.path.join(ROOT, "nerf_meets_mlx_amd")],
                          capture_output=True, text=True).stdout.strip()
     assert out == "", f"product path imports the oracle: {out}"
+
+
+def test_blender_loader_roundtrip(tmp_path):
+    """dataset/dataloader.py:20-111 on a tiny generated dataset (8x8 RGBA PNGs)."""
+    import json
+    from PIL import Image
+    from nerf_meets_mlx_amd.dataset.dataloader import load_blender_data, post_load_blender_data
+    rng = np.random.default_rng(0)
+    counts = {"train": 3, "val": 2, "test": 4}
+    for split, n in counts.items():
+        os.makedirs(tmp_path / split, exist_ok=True)
+        frames = []
+        for i in range(n):
+            arr = rng.integers(0, 256, size=(8, 8, 4), dtype=np.uint8)
+            Image.fromarray(arr, "RGBA").save(tmp_path / split / f"r_{i}.png")
+            frames.append({"file_path": f"./{split}/r_{i}", "transform_matrix": np.eye(4).tolist()})
+        with open(tmp_path / f"transforms_{split}.json", "w") as fp:
+            json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, fp)
+    imgs, poses, rposes, (H, W, f), i_split = load_blender_data(str(tmp_path), testskip=2)
+    assert imgs.shape == (3 + 1 + 2, 8, 8, 4) and imgs.dtype == np.float32 and poses.shape == (6, 4, 4)
+    assert [len(s) for s in i_split] == [3, 1, 2] and rposes.shape == (160, 4, 4)
+    assert abs(f - 0.5 * 8 / np.tan(0.5 * 0.6911112070083618)) < 1e-9
+    first = np.asarray(Image.open(tmp_path / "train" / "r_0.png")) / 255.0
+    np.testing.assert_allclose(imgs[0], first.astype(np.float32))
+    i_train, i_val, i_test, near, far, rgb = post_load_blender_data(i_split, imgs, True)
+    np.testing.assert_allclose(rgb, imgs[..., :3] * imgs[..., 3:] + (1 - imgs[..., 3:]))
+    assert (near, far) == (2.0, 6.0)
+    half = load_blender_data(str(tmp_path), half_res=True, testskip=1)
+    assert half[0].shape[1:3] == (4, 4) and abs(half[3][2] - f / 2) < 1e-9
