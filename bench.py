@@ -166,7 +166,7 @@ def cpu_baseline(args):
     torch.set_num_threads(cores)
     arch = O.NerfArch()
     tr = O.OracleTrainer(arch, 64, 128, seed=0)
-    b_train, b_render, steps = 32, 256, 2
+    b_train, b_render, steps = 256, 2048, 3
     g = torch.Generator().manual_seed(0)
     o = torch.nn.functional.normalize(torch.randn(b_render, 3, generator=g), dim=-1) * 4.0
     d = -o / 4.0 + 0.2 * torch.randn(b_render, 3, generator=g)

@@ -435,7 +435,7 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) dpe[t][ks] = row_frag(row + 63, ks, h, 27);
     } else {
-      const int64_t ray = m / a.n;
+      const int64_t ray = (int64_t)((unsigned)m / (unsigned)a.n);     // M < 2^31 (checked on the host): 32-bit divide
       const float* rr = a.rays + ray * NERF_RAY_STRIDE;
       const float zv = a.z[m];
       float p[3], d[3];
@@ -1046,6 +1046,7 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   NERF_REQUIRE(packed && rays && z && raw, NERF_E_NULL, "nerf_query_fused: NULL pointer");
   NERF_REQUIRE(n >= 1, NERF_E_SHAPE, "nerf_query_fused: n must be >= 1");
   NERF_REQUIRE(freq_mode == 0 || freq_mode == 1, NERF_E_UNSUPPORTED, "nerf_query_fused: freq_mode must be 0 or 1");
+  NERF_REQUIRE(B * (int64_t)n < (1ll << 31), NERF_E_SHAPE, "nerf_query_fused: B*n must be < 2^31 samples per call");
   if (B <= 0) return NERF_OK;
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
 }
