@@ -131,7 +131,9 @@ int nerf_mse_loss_grad(const float* pred, const float* target, int64_t count, fl
 /* ---------------------------------------------------------------- the MLP (a11, a12)
  * replaces: models/NeRF.py:160-243 (NeRF.__init__/forward), :10-48 (run_model),
  * models/embedding.py:4-21 (embed) for the architecture n_layers=8, width=256,
- * skips=[4], use_viewdirs, in_pos=63, in_dir=27 (anything else: NERF_E_UNSUPPORTED).
+ * skips=[4], use_viewdirs, in_pos=63, in_dir=27, and for the no-view-direction model of the reference's image
+ * fitting (entrypoints/__viser_image_learning.py:203-208: in_pos=40, in_dir=0, use_viewdirs=0, out_ch<=4; layers
+ * pos0 [256x40] pos1..4 pos5 [256x296] pos6 pos7 output [out_ch x 256]).  Anything else: NERF_E_UNSUPPORTED.
  *
  * Parameter layout (float32, flat, `nerf_mlp_param_count` = 595844 elements), each
  * layer as weight[out][in] row-major followed by bias[out]  (nn.Linear: x @ W^T + b):
@@ -145,6 +147,7 @@ typedef struct nerf_mlp_arch {
   int in_dir;       /* 27  */
   int skip_layer;   /* 4   */
   int use_viewdirs; /* 1   */
+  int out_ch;       /* outputs of `output_linear` when use_viewdirs == 0 (models/NeRF.py:196-197); ignored otherwise */
 } nerf_mlp_arch;
 
 int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch);
@@ -157,9 +160,12 @@ int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, void* packed, 
 int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M);
 int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M);
 
-/* NeRF.forward(x): x [M, 90] already embedded -> out [M,4] = [rgb, alpha] raw.          */
+/* NeRF.forward(x): x [M, in_pos+in_dir] already embedded -> out [M,4] = [rgb, alpha] raw (view model) or
+ * [M,out_ch] (image model).  The _train form also keeps the activations for nerf_mlp_backward.              */
 int nerf_mlp_forward(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M, float* out,
                      void* stream);
+int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M, float* out,
+                           void* acts, void* stream);
 
 /* network_query_fn(pts, viewdirs, model) fused with pts = o + z d and both positional
  * encodings (models/NeRF.py:75-80 + rendering/render.py:142,226): rays [B,11], z [B,n]

@@ -36,6 +36,7 @@ SIGNATURES = {
     "nerf_mlp_acts_bytes": (_I64, [_P, _I64]),
     "nerf_mlp_dz_bytes": (_I64, [_P, _I64]),
     "nerf_mlp_forward": (_I, [_P, _P, _P, _I64, _P, _P]),
+    "nerf_mlp_forward_train": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "nerf_query_fused": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
     "nerf_mlp_backward": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P]),
     "nerf_set_option": (_I, [C.c_char_p, _I]),
@@ -46,7 +47,7 @@ SIGNATURES = {
 class MlpArch(C.Structure):
     """struct nerf_mlp_arch (include/nerf_hip.h)."""
     _fields_ = [("n_layers", _I), ("width", _I), ("in_pos", _I), ("in_dir", _I), ("skip_layer", _I),
-                ("use_viewdirs", _I)]
+                ("use_viewdirs", _I), ("out_ch", _I)]
 
 
 class NerfHipError(RuntimeError):

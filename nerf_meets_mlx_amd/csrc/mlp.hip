@@ -938,6 +938,218 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
   }
 }
 
+
+// ==========================================================================================
+// Second architecture: the no-view-direction model of the reference's 2-D image fitting
+// (entrypoints/__viser_image_learning.py:198-208: NeRF(channel_input=40, channel_input_views=0, channel_output=3,
+// is_use_view_directions=False)): pos0 [256x40] pos1..4 [256x256] pos5 [256x296] pos6 pos7 output [out_ch x 256]
+// (models/NeRF.py:182-197,241).  Same register-resident transposed scheme, same ring, same dW kernel.
+// ==========================================================================================
+namespace LI {
+constexpr int CIN = 40;
+constexpr int P_W0 = 0, P_B0 = 10240, P_W1 = 10496, P_W5 = 273664, P_B5 = 349440;
+constexpr int P_W6 = 349696, P_B6 = 415232, P_W7 = 415488, P_B7 = 481024, P_WO = 481280;
+__host__ __device__ constexpr int pw(int l) {
+  return l == 0 ? P_W0 : l <= 4 ? P_W1 + (l - 1) * 65792 : l == 5 ? P_W5 : l == 6 ? P_W6 : P_W7;
+}
+__host__ __device__ constexpr int pb(int l) {
+  return l == 0 ? P_B0 : l <= 4 ? P_W1 + (l - 1) * 65792 + 65536 : l == 5 ? P_B5 : l == 6 ? P_B6 : P_B7;
+}
+constexpr int F_L0 = 0, F_L1 = 24, F_L5 = 536, F_L6 = 688, F_L7 = 816, F_OUT = 944, F_TOTAL = 960;
+constexpr int B_OUT = 0, B_L7 = 8, B_TOTAL = 904, B_PADDED = 928;       // OUT^T, pos7..pos1 (pos5: H4 columns)
+constexpr int BI_OUT = 2048, BI_TOTAL = 2080;
+constexpr int A_X = 0, A_H0 = 3, A_MASK = 131, A_SLOTS = 139;
+constexpr int Z_L0 = 0, Z_OUT = 128, Z_SLOTS = 129;
+constexpr int F_CHUNKS = F_TOTAL / RING_CHUNK, B_CHUNKS = B_PADDED / RING_CHUNK;   // 30, 29
+static_assert(F_CHUNKS * RING_CHUNK == F_TOTAL && B_CHUNKS * RING_CHUNK == B_PADDED, "whole chunks");
+}  // namespace LI
+
+__device__ float fwd_src_img(const float* __restrict__ p, int f, int r, int h, int j, int out_ch) {
+  if (f < LI::F_L1) {                                  // pos0: K space 48 (40 + pad)
+    const int nt = f / 3, ks = f % 3, kk = kperm(ks, h, j);
+    return kk < 40 ? p[LI::P_W0 + (32 * nt + r) * 40 + kk] : 0.0f;
+  }
+  if (f < LI::F_L5) {
+    const int l = 1 + (f - LI::F_L1) / 128, g = (f - LI::F_L1) % 128;
+    return p[LI::pw(l) + (32 * (g / 16) + r) * 256 + kperm(g % 16, h, j)];
+  }
+  if (f < LI::F_L6) {                                  // pos5: [x(48), H4(256)] vs W5[256][296]
+    const int g = f - LI::F_L5, nt = g / 19, ks = g % 19, kk = kperm(ks, h, j), n = 32 * nt + r;
+    if (kk < 48) return kk < 40 ? p[LI::P_W5 + n * 296 + kk] : 0.0f;
+    return p[LI::P_W5 + n * 296 + 40 + (kk - 48)];
+  }
+  if (f < LI::F_OUT) {
+    const int l = 6 + (f - LI::F_L6) / 128, g = (f - LI::F_L6) % 128;
+    return p[LI::pw(l) + (32 * (g / 16) + r) * 256 + kperm(g % 16, h, j)];
+  }
+  return r < out_ch ? p[LI::P_WO + r * 256 + kperm(f - LI::F_OUT, h, j)] : 0.0f;
+}
+
+__device__ float bwd_src_img(const float* __restrict__ p, int f, int r, int h, int j, int out_ch) {
+  if (f < LI::B_L7) {                                  // output^T: 8 tiles of H7, one k-step (rows 0..out_ch-1)
+    const int nn = kperm(0, h, j);
+    return nn < out_ch ? p[LI::P_WO + nn * 256 + 32 * f + r] : 0.0f;
+  }
+  const int g = f - LI::B_L7, li = g / 128, q = g % 128, kt = q / 16, ns = q % 16;
+  const int l = 7 - li, nn = kperm(ns, h, j), row = 32 * kt + r;
+  if (l == 5) return p[LI::P_W5 + nn * 296 + 40 + row];
+  return p[LI::pw(l) + nn * 256 + row];
+}
+
+__global__ void __launch_bounds__(256) pack_img_kernel(const float* __restrict__ p, bf16x8* __restrict__ wf,
+                                                       bf16x8* __restrict__ wb, float* __restrict__ bias, int out_ch) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int nf = LI::F_TOTAL * 64, nb = LI::B_PADDED * 64;
+  if (tid < nf + nb) {
+    const bool fw = tid < nf;
+    const int t = fw ? tid : tid - nf;
+    const int f = t >> 6, lane = t & 63, r = lane & 31, h = lane >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = (__bf16)(fw ? fwd_src_img(p, f, r, h, j, out_ch) : (f < LI::B_TOTAL ? bwd_src_img(p, f, r, h, j, out_ch) : 0.0f));
+    (fw ? wf : wb)[t] = v;
+  } else if (tid < nf + nb + LI::BI_TOTAL) {
+    const int s = tid - nf - nb;
+    bias[s] = s < 2048 ? p[LI::pb(s >> 8) + (s & 255)] : ((s - LI::BI_OUT) < out_ch ? p[LI::P_WO + out_ch * 256 + (s - LI::BI_OUT)] : 0.0f);
+  }
+}
+
+struct ImgArgs {
+  const bf16x8* wf; const bf16x8* wb; const float* bias;
+  const float* x;        // [M,40] embedded rows
+  const float* d_out;    // [M,out_ch]
+  int64_t M; int out_ch;
+  float* out;            // [M,out_ch]
+  void* acts; void* dz;
+  int64_t astride, zstride;
+};
+
+template <bool STORE, class WS>
+__device__ __forceinline__ void fwd_tiles_img(const ImgArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane) {
+  constexpr int ST = 1;
+  const int r = lane & 31, h = lane >> 5;
+  int64_t tile = tile0 < ntiles ? tile0 : ntiles - 1;
+  int64_t m = tile * 32 + r; if (m >= a.M) m = a.M - 1;
+  bf16x8 xin[ST][3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) xin[0][ks] = row_frag(a.x + m * LI::CIN, ks, h, LI::CIN);
+  if (STORE) store_frags<3>(a.acts, tile0, a.astride, LI::A_X, xin[0], r, h);
+  bf16x8 ha[ST][16], hb[ST][16];
+  u32x4 mk[ST];
+#define IMG_LAYER(KS, FB, BS, IN, OUT, LYR)                                                        \
+  do { mk[0] = u32x4{0u, 0u, 0u, 0u};                                                              \
+       layer_fwd<ST, KS, 8, true, STORE>(ws, FB, BS, IN, OUT, mk, lane);                           \
+       if (STORE) { store_frags<16>(a.acts, tile0, a.astride, LI::A_H0 + 16 * (LYR), OUT[0], r, h); \
+                    *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0, a.astride, LI::A_MASK + (LYR), r, h)) = mk[0]; } } while (0)
+  IMG_LAYER(3, LI::F_L0, 0, xin, ha, 0);
+  IMG_LAYER(16, LI::F_L1 + 0 * 128, 256, ha, hb, 1);
+  IMG_LAYER(16, LI::F_L1 + 1 * 128, 512, hb, ha, 2);
+  IMG_LAYER(16, LI::F_L1 + 2 * 128, 768, ha, hb, 3);
+  IMG_LAYER(16, LI::F_L1 + 3 * 128, 1024, hb, ha, 4);
+  {
+    bf16x8 cat[ST][19];
+    if (STORE) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xin[0][k] = *frag_ptr(a.acts, tile0, a.astride, LI::A_X + k, r, h);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cat[0][k] = xin[0][k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cat[0][3 + k] = ha[0][k];
+    IMG_LAYER(19, LI::F_L5, 1280, cat, hb, 5);           // concat [input_pos, h]  models/NeRF.py:224-225
+  }
+  IMG_LAYER(16, LI::F_L6, 1536, hb, ha, 6);
+  IMG_LAYER(16, LI::F_L7, 1792, ha, hb, 7);
+#undef IMG_LAYER
+  f32x16 acc;
+  acc_init_bias(acc, ws, LI::BI_OUT, h);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const bf16x8 wo = next_frag(ws, LI::F_OUT + ks, lane);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, hb[0][ks], acc, 0, 0, 0);
+  }
+  const int64_t mo = tile0 * 32 + r;
+  if (h == 0 && tile0 < ntiles && mo < a.M) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < a.out_ch) a.out[mo * a.out_ch + c] = acc[c];                     // output_linear (models/NeRF.py:241)
+  }
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(512, 2) mlp_img_fwd_ring_kernel(ImgArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ntiles = (a.M + 31) >> 5, nsuper = (ntiles + 7) >> 3;
+  RingW<LI::F_CHUNKS, LI::F_TOTAL, (STORE ? 2 : 4)> ws;
+  ws.wsrc = reinterpret_cast<const char*>(a.wf);
+  ws.lane16 = 16 * lane;
+  ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
+  ws.wv = wv;
+  ws.start(lane);
+  ring_load_bias(a.bias, LI::BI_TOTAL);
+  __syncthreads();
+  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    fwd_tiles_img<STORE>(a, ws, sp * 8 + wv, ntiles, ln);
+  }
+  ws.drain();
+}
+
+__global__ void __launch_bounds__(512, 2) mlp_img_bwd_ring_kernel(ImgArgs a) {
+  constexpr int ST = 1;
+  const int lane0 = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ntiles = (a.M + 31) >> 5, nsuper = (ntiles + 7) >> 3;
+  RingW<LI::B_CHUNKS, LI::B_TOTAL> ws;
+  ws.wsrc = reinterpret_cast<const char*>(a.wb);
+  ws.lane16 = 16 * lane0;
+  ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
+  ws.wv = wv;
+  ws.start(lane0);
+  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t tile0 = sp * 8 + wv;
+    const int64_t tile = tile0 < ntiles ? tile0 : ntiles - 1;
+    const int64_t m = tile * 32 + r;
+    bf16x8 zo[ST][1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zo[0][0][j] = (__bf16)0.0f;
+    if (tile0 < ntiles && m < a.M && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < a.out_ch) zo[0][0][c] = (__bf16)a.d_out[m * a.out_ch + c];      // rows 0..out_ch-1
+    }
+    u32x4 mk[8][ST];
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      mk[l][0] = *reinterpret_cast<const u32x4*>(frag_ptr(a.acts, tile, a.astride, LI::A_MASK + l, r, h));
+    store_frags<1>(a.dz, tile0, a.zstride, LI::Z_OUT, zo[0], r, h);
+    bf16x8 za[ST][16], zb[ST][16];
+    layer_bwd<ST, 1, 8, true>(ws, LI::B_OUT, zo, zb, mk[7], lane);                                  // dZ7
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 112, zb[0], r, h);
+    layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 0 * 128, zb, za, mk[6], lane);                        // dZ6
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 96, za[0], r, h);
+    layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 1 * 128, za, zb, mk[5], lane);                        // dZ5
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 80, zb[0], r, h);
+    layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 2 * 128, zb, za, mk[4], lane);                        // dZ4
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 64, za[0], r, h);
+    layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 3 * 128, za, zb, mk[3], lane);                        // dZ3
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 48, zb[0], r, h);
+    layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 4 * 128, zb, za, mk[2], lane);                        // dZ2
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 32, za[0], r, h);
+    layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 5 * 128, za, zb, mk[1], lane);                        // dZ1
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 16, zb[0], r, h);
+    layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 6 * 128, zb, za, mk[0], lane);                        // dZ0
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 0, za[0], r, h);
+  }
+  ws.drain();
+}
+
 static int g_dw_wgs = 768;
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
 static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
@@ -950,10 +1162,17 @@ static void ensure_lds(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-static bool arch_ok(const nerf_mlp_arch* a) {
-  return a && a->n_layers == 8 && a->width == 256 && a->in_pos == 63 && a->in_dir == 27 && a->skip_layer == 4 &&
-         a->use_viewdirs == 1;
+// 0: the NeRF view model (63+27 -> 4), 1: the image-fitting model (40 -> out_ch), -1: no HIP kernel
+static int arch_kind(const nerf_mlp_arch* a) {
+  if (!a || a->n_layers != 8 || a->width != 256 || a->skip_layer != 4) return -1;
+  if (a->use_viewdirs == 1 && a->in_pos == 63 && a->in_dir == 27) return 0;
+  if (a->use_viewdirs == 0 && a->in_pos == 40 && a->out_ch >= 1 && a->out_ch <= 4) return 1;
+  return -1;
 }
+static bool arch_ok(const nerf_mlp_arch* a) { return arch_kind(a) == 0; }
+static inline int64_t img_astride16() { return (int64_t)LI::A_SLOTS * 64 + g_tile_pad16; }
+static inline int64_t img_zstride16() { return (int64_t)LI::Z_SLOTS * 64 + g_tile_pad16; }
+static inline int64_t img_params(const nerf_mlp_arch* a) { return LI::P_WO + (int64_t)a->out_ch * 257; }
 
 }  // namespace nerf
 
@@ -968,22 +1187,43 @@ extern "C" int nerf_set_option(const char* key, int value) {
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
-extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) { return arch_ok(arch) ? L::P_TOTAL : -1; }
-extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) { return arch_ok(arch) ? L::PACKED_BYTES : -1; }
+extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) {
+  const int k = arch_kind(arch);
+  return k == 0 ? L::P_TOTAL : k == 1 ? img_params(arch) : -1;
+}
+extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) {
+  const int k = arch_kind(arch);
+  return k == 0 ? L::PACKED_BYTES : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : -1;
+}
+static inline int64_t padded_tiles(int64_t M) { return (((M + 31) / 32) + 7) / 8 * 8; }
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
-  return arch_ok(arch) && M >= 0 ? ((((M + 31) / 32) + 7) / 8 * 8) * astride16() * 16 : -1;
+  const int k = arch_kind(arch);
+  if (k < 0 || M < 0) return -1;
+  return padded_tiles(M) * (k == 0 ? astride16() : img_astride16()) * 16;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
-  return arch_ok(arch) && M >= 0 ? ((((M + 31) / 32) + 7) / 8 * 8) * zstride16() * 16 : -1;
+  const int k = arch_kind(arch);
+  if (k < 0 || M < 0) return -1;
+  return padded_tiles(M) * (k == 0 ? zstride16() : img_zstride16()) * 16;
 }
 
-#define NERF_ARCH_CHECK(who) \
-  NERF_REQUIRE(arch_ok(arch), NERF_E_UNSUPPORTED, who ": only n_layers=8,width=256,in_pos=63,in_dir=27,skip=4,use_viewdirs=1 is implemented")
+#define NERF_ARCH_MSG ": HIP kernels exist for (8x256, skip 4) with in=63+27 view head, or in=40 / no view head / out_ch<=4"
+#define NERF_ARCH_CHECK(who) NERF_REQUIRE(arch_ok(arch), NERF_E_UNSUPPORTED, who NERF_ARCH_MSG)
+#define NERF_ARCH_CHECK_ANY(who) NERF_REQUIRE(arch_kind(arch) >= 0, NERF_E_UNSUPPORTED, who NERF_ARCH_MSG)
 
 extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, void* packed, void* stream) {
-  NERF_ARCH_CHECK("nerf_mlp_pack");
+  NERF_ARCH_CHECK_ANY("nerf_mlp_pack");
   NERF_REQUIRE(params && packed, NERF_E_NULL, "nerf_mlp_pack: params/packed is NULL");
   char* base = static_cast<char*>(packed);
+  if (arch_kind(arch) == 1) {
+    bf16x8* wfi = reinterpret_cast<bf16x8*>(base);
+    bf16x8* wbi = reinterpret_cast<bf16x8*>(base + (size_t)LI::F_TOTAL * 1024);
+    float* bi = reinterpret_cast<float*>(base + (size_t)(LI::F_TOTAL + LI::B_PADDED) * 1024);
+    const int tot = (LI::F_TOTAL + LI::B_PADDED) * 64 + LI::BI_TOTAL;
+    hipLaunchKernelGGL(pack_img_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), params, wfi, wbi, bi,
+                       arch->out_ch);
+    return check_launch("nerf_mlp_pack (image model)");
+  }
   bf16x8* wf = reinterpret_cast<bf16x8*>(base);
   bf16x8* wb = reinterpret_cast<bf16x8*>(base + (size_t)L::F_TOTAL * 1024);
   float* bias = reinterpret_cast<float*>(base + (size_t)(L::F_TOTAL + L::B_PADDED) * 1024);
@@ -1032,12 +1272,38 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   return check_launch("mlp forward");
 }
 
+static void img_args(ImgArgs& a, const nerf_mlp_arch* arch, const void* packed) {
+  const char* base = static_cast<const char*>(packed);
+  a.wf = reinterpret_cast<const bf16x8*>(base);
+  a.wb = reinterpret_cast<const bf16x8*>(base + (size_t)LI::F_TOTAL * 1024);
+  a.bias = reinterpret_cast<const float*>(base + (size_t)(LI::F_TOTAL + LI::B_PADDED) * 1024);
+  a.out_ch = arch->out_ch; a.astride = img_astride16(); a.zstride = img_zstride16();
+  a.x = nullptr; a.d_out = nullptr; a.out = nullptr; a.acts = nullptr; a.dz = nullptr; a.M = 0;
+}
+
+extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M,
+                                      float* out, void* acts, void* stream) {
+  NERF_ARCH_CHECK_ANY("nerf_mlp_forward");
+  if (M <= 0) return NERF_OK;
+  NERF_REQUIRE(packed && x && out, NERF_E_NULL, "nerf_mlp_forward: NULL pointer");
+  if (arch_kind(arch) == 1) {
+    ImgArgs a;
+    img_args(a, arch, packed);
+    a.x = x; a.out = out; a.acts = acts; a.M = M;
+    const int64_t nsuper = ((M + 31) / 32 + 7) / 8;
+    static bool once = false;
+    if (!once) { ensure_lds(mlp_img_fwd_ring_kernel<true>, RING_LDS_BYTES); ensure_lds(mlp_img_fwd_ring_kernel<false>, RING_LDS_BYTES); once = true; }
+    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
+    if (acts) hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<true>, g, b, RING_LDS_BYTES, as_stream(stream), a);
+    else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
+    return check_launch("mlp forward (image model)");
+  }
+  return launch_fwd<0>(packed, x, nullptr, nullptr, M, 1, 0, out, acts, stream);
+}
+
 extern "C" int nerf_mlp_forward(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M, float* out,
                                 void* stream) {
-  NERF_ARCH_CHECK("nerf_mlp_forward");
-  NERF_REQUIRE(packed && x && out, NERF_E_NULL, "nerf_mlp_forward: NULL pointer");
-  if (M <= 0) return NERF_OK;
-  return launch_fwd<0>(packed, x, nullptr, nullptr, M, 1, 0, out, nullptr, stream);
+  return nerf_mlp_forward_train(arch, packed, x, M, out, nullptr, stream);
 }
 
 extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
@@ -1051,13 +1317,74 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
 }
 
+// split the (dZ, H) jobs over workgroups and launch the dW kernel; grads[0..nparams) is overwritten
+static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
+                     int64_t zstride, float* grads, hipStream_t s) {
+  // The dW pass is HBM-bound (every dZ / activation byte is read once per job, 128 FLOP/B), so a job's cost is
+  // its bytes per sample tile (nf + kf KiB).  One workgroup per CU (148 KiB LDS each): split the sample range of
+  // every job over ~256 workgroups in proportion to those bytes so that all of them finish together.
+  int64_t units[DW_MAX_JOBS], total_units = 0;
+  for (int j = 0; j < nj; ++j) {
+    units[j] = d.jobs[j].nf + d.jobs[j].kf;
+    total_units += units[j];
+  }
+  const int target_wgs = g_dw_wgs;
+  int nw = 0;
+  for (int j = 0; j < DW_MAX_JOBS; ++j) d.splits[j] = 0;
+  for (int j = 0; j < nj; ++j) {
+    int64_t splits = (units[j] * target_wgs + total_units / 2) / total_units;
+    const int64_t max_splits = (ntiles + 3) / 4;              // >= 4 sample tiles per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    d.splits[j] = (int)splits;
+    nw += (int)splits;
+  }
+  hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * nparams, s);
+  if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
+  d.ntiles = (int)ntiles; d.astride = astride; d.zstride = zstride;
+  d.acts = acts; d.dz = dz; d.grads = grads;
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    lds_attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(512), DW_LDS_BYTES, s, d);
+  return check_launch("mlp dW");
+}
+
 extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
                                  int64_t M, void* dz, float* grads, void* stream) {
-  NERF_ARCH_CHECK("nerf_mlp_backward");
+  NERF_ARCH_CHECK_ANY("nerf_mlp_backward");
   NERF_REQUIRE(packed && acts && d_raw && dz && grads, NERF_E_NULL, "nerf_mlp_backward: NULL pointer");
   NERF_REQUIRE(M > 0, NERF_E_SHAPE, "nerf_mlp_backward: M must be > 0");
   auto s = as_stream(stream);
   const int64_t ntiles = (M + 31) / 32;
+  if (arch_kind(arch) == 1) {
+    ImgArgs a;
+    img_args(a, arch, packed);
+    a.d_out = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M;
+    const int64_t nsuper = (ntiles + 7) / 8;
+    static bool once_i = false;
+    if (!once_i) { ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES); once_i = true; }
+    hipLaunchKernelGGL(mlp_img_bwd_ring_kernel, dim3((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), dim3(512),
+                       RING_LDS_BYTES, s, a);
+    int rci = check_launch("mlp backward chain (image model)");
+    if (rci) return rci;
+    DwArgs di;
+    int nji = 0;
+    auto jobi = [&](int dz_slot, int nf, int act_slot, int kf, int w_off, int ldw, int col0, int nv, int kv, int b_off) {
+      di.jobs[nji++] = DwJob{dz_slot, nf, act_slot, kf, w_off, ldw, col0, nv, kv, b_off};
+    };
+    jobi(LI::Z_L0, 16, LI::A_X, 3, LI::P_W0, 40, 0, 256, 40, LI::P_B0);                                    // pos0
+    for (int l = 1; l <= 4; ++l)
+      jobi(LI::Z_L0 + 16 * l, 16, LI::A_H0 + 16 * (l - 1), 16, LI::pw(l), 256, 0, 256, 256, LI::pb(l));    // pos1..4
+    jobi(LI::Z_L0 + 80, 16, LI::A_H0 + 64, 16, LI::P_W5, 296, 40, 256, 256, LI::P_B5);                     // pos5 | H4
+    jobi(LI::Z_L0 + 80, 16, LI::A_X, 3, LI::P_W5, 296, 0, 256, 40, -1);                                    // pos5 | x
+    jobi(LI::Z_L0 + 96, 16, LI::A_H0 + 80, 16, LI::P_W6, 256, 0, 256, 256, LI::P_B6);                      // pos6
+    jobi(LI::Z_L0 + 112, 16, LI::A_H0 + 96, 16, LI::P_W7, 256, 0, 256, 256, LI::P_B7);                     // pos7
+    jobi(LI::Z_OUT, 1, LI::A_H0 + 112, 16, LI::P_WO, 256, 0, arch->out_ch, 256, LI::P_WO + arch->out_ch * 256);   // output
+    return launch_dw(di, nji, ntiles, img_params(arch), acts, dz, img_astride16(), img_zstride16(), grads, s);
+  }
   // ---- 1. dZ chain
   BwdArgs b;
   b.wb = reinterpret_cast<const bf16x8*>(static_cast<const char*>(packed) + (size_t)L::F_TOTAL * 1024);
@@ -1095,34 +1422,5 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   job(L::Z_D, 8, L::A_FEAT, 16, L::P_WD, 283, 0, 128, 256, L::P_BD);                               // dir0 | feature
   job(L::Z_D, 8, L::A_DPE, 2, L::P_WD, 283, 256, 128, 27, -1);                                     // dir0 | dirPE
   job(L::Z_RGB, 1, L::A_HD, 8, L::P_WR, 128, 0, 3, 128, L::P_BR);                                  // rgb
-  // The dW pass is HBM-bound (every dZ / activation byte is read once per job, 128 FLOP/B), so a job's cost is
-  // its bytes per sample tile (nf + kf KiB).  One workgroup per CU (148 KiB LDS each): split the sample range of
-  // every job over ~256 workgroups in proportion to those bytes so that all of them finish together.
-  int64_t units[DW_MAX_JOBS], total_units = 0;
-  for (int j = 0; j < nj; ++j) {
-    units[j] = d.jobs[j].nf + d.jobs[j].kf;
-    total_units += units[j];
-  }
-  const int target_wgs = g_dw_wgs;
-  int nw = 0;
-  for (int j = 0; j < DW_MAX_JOBS; ++j) d.splits[j] = 0;
-  for (int j = 0; j < nj; ++j) {
-    int64_t splits = (units[j] * target_wgs + total_units / 2) / total_units;
-    const int64_t max_splits = (ntiles + 3) / 4;              // >= 4 sample tiles per workgroup
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    d.splits[j] = (int)splits;
-    nw += (int)splits;
-  }
-  hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * L::P_TOTAL, s);
-  if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
-  d.ntiles = (int)ntiles; d.astride = astride16(); d.zstride = zstride16();
-  d.acts = acts; d.dz = dz; d.grads = grads;
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-    lds_attr_set = true;
-  }
-  hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(512), DW_LDS_BYTES, s, d);
-  return check_launch("mlp dW");
+  return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astride16(), zstride16(), grads, s);
 }

@@ -48,7 +48,8 @@ class NeRF:
         self.n_params = sum(o * i + o for _, o, i in self.shapes)
         self.arch = N.MlpArch(n_layers, width_layers, channel_input, channel_input_views,
                               self.list_skip_connection_layers[0] if len(self.list_skip_connection_layers) == 1 else -1,
-                              int(bool(is_use_view_directions)))
+                              int(bool(is_use_view_directions)), channel_output)
+        self.out_dim = 4 if is_use_view_directions else channel_output
         rng = np.random.default_rng(seed)
         chunks = []
         for _, o, i in self.shapes:
@@ -89,8 +90,8 @@ class NeRF:
         if self._packed is None:
             nbytes = lib.nerf_mlp_packed_bytes(C.byref(self.arch))
             if nbytes < 0:
-                raise ValueError("libnerf_hip error -3: this NeRF architecture has no HIP kernel (supported: "
-                                 "n_layers=8, width=256, in=63+27, skips=[4], view directions on)")
+                raise ValueError("libnerf_hip error -3: this NeRF architecture has no HIP kernel (supported: n_layers=8, "
+                                 "width=256, skips=[4] with in=63+27 + view head, or in=40 without view head and out<=4)")
             self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         if self._dirty:
             N.check(lib.nerf_mlp_pack(C.byref(self.arch), N.ptr(self.params), N.ptr(self._packed), N.stream()))
@@ -105,11 +106,18 @@ class NeRF:
         return t
 
     # ---- NeRF.forward(x) on embedded rows (models/NeRF.py:201-243) -----------------------------
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, train: bool = False) -> torch.Tensor:
+        """Embedded rows [M, C_in] -> [M, 4] (view model: rgb, alpha) or [M, channel_output].  train=True keeps the
+        activations for `backward` (the reference gets gradients from nn.value_and_grad around this call)."""
         x = N.f32(x).reshape(-1, x.shape[-1])
-        out = torch.empty(x.shape[0], 4, dtype=torch.float32, device=x.device)
-        N.check(N.lib().nerf_mlp_forward(C.byref(self.arch), N.ptr(self.packed()), N.ptr(x), x.shape[0], N.ptr(out),
-                                         N.stream()))
+        M = x.shape[0]
+        out = torch.empty(M, self.out_dim, dtype=torch.float32, device=x.device)
+        acts = None
+        if train:
+            acts = self._workspace("acts", N.lib().nerf_mlp_acts_bytes(C.byref(self.arch), M))
+            self._acts_M = M
+        N.check(N.lib().nerf_mlp_forward_train(C.byref(self.arch), N.ptr(self.packed()), N.ptr(x), M, N.ptr(out),
+                                               N.ptr(acts), N.stream()))
         return out
 
     __call__ = forward
@@ -128,8 +136,9 @@ class NeRF:
 
     def backward(self, d_raw: torch.Tensor) -> torch.Tensor:
         """Parameter gradients of the last `query(..., train=True)`; overwrites self.grads."""
-        M = d_raw.numel() // 4
-        assert M == getattr(self, "_acts_M", -1), "backward() needs a matching query(train=True) first"
+        d_raw = N.f32(d_raw)
+        M = d_raw.numel() // self.out_dim
+        assert M == getattr(self, "_acts_M", -1), "backward() needs a matching query/forward(train=True) first"
         dz = self._workspace("dz", N.lib().nerf_mlp_dz_bytes(C.byref(self.arch), M))
         N.check(N.lib().nerf_mlp_backward(C.byref(self.arch), N.ptr(self.packed()), N.ptr(self._ws["acts"]),
                                           N.ptr(d_raw), M, N.ptr(dz), N.ptr(self.grads), N.stream()))

@@ -590,3 +590,30 @@ class OracleTrainer:
         self.it += 1
         self.lr = lr_schedule(self.lrate, self.decay, self.it)
         return out
+
+
+# --------------------------------------------------------------------------------------
+# 2-D image fitting loop (entrypoints/__viser_image_learning.py:86-124, 198-236, 271-288)
+# --------------------------------------------------------------------------------------
+
+class OracleImageFitter:
+    """embed = SinusoidalEncoding(2, 10, 0, 8) (:198); NeRF(40 -> 3, no view head) (:203-208);
+    Adam(lr 1e-3, betas (0.9, 0.99)) (:224-227); loss = mean((model(embed(X)) - y)^2) (:210-219);
+    X are INTEGER (row, col) pixel coordinates (:86-124)."""
+
+    def __init__(self, seed: int = 0, lr: float = 1e-3, emulate_bf16: bool = False):
+        self.arch = NerfArch(channel_input=40, channel_input_views=0, channel_output=3, use_viewdirs=False)
+        self.p = flatten_params(self.arch, init_params(self.arch, seed)).requires_grad_(True)
+        self.m, self.v = torch.zeros_like(self.p), torch.zeros_like(self.p)
+        self.lr, self.emu = lr, emulate_bf16
+
+    def forward(self, X):
+        x = sinusoidal_encoding(X, 10, 0.0, 8.0, False)
+        return nerf_forward(self.arch, unflatten_params(self.arch, self.p), x, self.emu)
+
+    def step(self, X, y):
+        loss = mse(self.forward(X), y)
+        g, = torch.autograd.grad(loss, self.p)
+        with torch.no_grad():
+            adam_step(self.p, g, self.m, self.v, self.lr, b1=0.9, b2=0.99)
+        return float(loss.detach()), g

@@ -41,11 +41,13 @@ def test_host_argument_validation_without_gpu():
     assert b"NULL" in lib.nerf_last_error()
     assert lib.nerf_importance_sample(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 4, 300, 8, 1e-5, None, None, None,
                                       None, None) == -2                      # NERF_E_SHAPE
-    arch = _native.MlpArch(8, 256, 63, 27, 4, 1)
+    arch = _native.MlpArch(8, 256, 63, 27, 4, 1, 4)
     assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844
     assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == (1184 + 1120) * 1024 + 2496 * 4
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
-    bad = _native.MlpArch(8, 128, 63, 27, 4, 1)
+    img = _native.MlpArch(8, 256, 40, 0, 4, 0, 3)
+    assert lib.nerf_mlp_param_count(C.byref(img)) == 482051
+    bad = _native.MlpArch(8, 128, 63, 27, 4, 1, 4)
     assert lib.nerf_mlp_param_count(C.byref(bad)) == -1
     with pytest.raises(ValueError):
         _native.ptr(torch.zeros(3))                                          # CPU tensors are refused: no fallback
