@@ -181,6 +181,29 @@ int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, const float*
 int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
                       int64_t M, void* dz, float* grads, void* stream);
 
+/* ---------------------------------------------------------------- fused renderer (a14 / a18)
+ * replaces: rendering/render.py:164-241 render_rays_eval (coarse pass, importance sampling, sort, second pass)
+ * as ONE call that enqueues the fixed kernel sequence on `stream`: nerf_sample_coarse -> nerf_query_fused ->
+ * nerf_composite_forward -> nerf_importance_sample -> nerf_query_fused -> nerf_composite_forward.
+ * workspace: nerf_render_workspace_bytes(B,n,N) bytes of scratch.  packed_fine NULL = network_coarse
+ * (render.py:228).  N == 0: coarse result only.  Optional outputs may be NULL.  u [B,N] = the uniforms that
+ * sampling/__init__.py:140 draws with torch.rand.                                                          */
+int64_t nerf_render_workspace_bytes(int64_t B, int n, int N);
+int nerf_render_rays_fused(const nerf_mlp_arch* arch, const void* packed_coarse, const void* packed_fine,
+                           const float* rays, int64_t B, int n, int N, const float* u, int freq_mode, int white_bkgd,
+                           void* workspace, float* rgb, float* disp, float* acc, float* rgb_coarse, float* disp_coarse,
+                           float* acc_coarse, float* z_vals, float* weights, void* stream);
+
+/* ---------------------------------------------------------------- gradient all-reduce (no reference
+ * counterpart: the reference is single-device).  RCCL over xGMI, one in-place float32 sum of the flat gradient
+ * buffer per network step.  id: 128 host bytes from nerf_comm_unique_id on rank 0, distributed by the caller.
+ * librccl is resolved at first use (NERF_E_RCCL when it is not installed).                                  */
+#define NERF_COMM_ID_BYTES 128
+int nerf_comm_unique_id(char* id_out_host);
+int nerf_comm_init(void** comm_out, int nranks, int rank, const char* id_host);
+int nerf_allreduce_grads(void* comm, float* grads, int64_t count, void* stream);
+int nerf_comm_destroy(void* comm);
+
 /* runtime selection of kernel variants (for A/B measurement): key "mlp_variant"        */
 int nerf_set_option(const char* key, int value);
 

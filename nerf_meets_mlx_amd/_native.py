@@ -39,6 +39,12 @@ SIGNATURES = {
     "nerf_mlp_forward_train": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "nerf_query_fused": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
     "nerf_mlp_backward": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P]),
+    "nerf_render_workspace_bytes": (_I64, [_I64, _I, _I]),
+    "nerf_render_rays_fused": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_comm_unique_id": (_I, [C.c_char_p]),
+    "nerf_comm_init": (_I, [C.POINTER(C.c_void_p), _I, _I, C.c_char_p]),
+    "nerf_allreduce_grads": (_I, [_P, _P, _I64, _P]),
+    "nerf_comm_destroy": (_I, [_P]),
     "nerf_set_option": (_I, [C.c_char_p, _I]),
     "nerf_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _I, _F, _P]),
 }

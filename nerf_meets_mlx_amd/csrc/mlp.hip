@@ -1150,7 +1150,7 @@ __global__ void __launch_bounds__(512, 2) mlp_img_bwd_ring_kernel(ImgArgs a) {
   ws.drain();
 }
 
-static int g_dw_wgs = 768;
+static int g_dw_wgs = 0;       // 0: automatic (see launch_dw)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
 static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
 static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad16; }
@@ -1183,7 +1183,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "mlp_variant")) { g_mlp_variant = value; return NERF_OK; }
   if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 256; return NERF_OK; }
   if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
-  if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 256; return NERF_OK; }
+  if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 0; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -1328,7 +1328,15 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
     units[j] = d.jobs[j].nf + d.jobs[j].kf;
     total_units += units[j];
   }
-  const int target_wgs = g_dw_wgs;
+  // Workgroups are dealt to CUs as they free up, so many short ones balance better than 256 long ones: about 80
+  // sample tiles per workgroup measured best (B=4096: n=64 -> ~1500 workgroups, n=192 -> ~3000+); the atomic flush
+  // (<= 256 KiB per workgroup) stays < 5 % of a workgroup's life at that size.
+  int target_wgs = g_dw_wgs;
+  if (target_wgs <= 0) {
+    target_wgs = (int)(ntiles * nj / 80);
+    if (target_wgs < 256) target_wgs = 256;
+    if (target_wgs > 4096) target_wgs = 4096;
+  }
   int nw = 0;
   for (int j = 0; j < DW_MAX_JOBS; ++j) d.splits[j] = 0;
   for (int j = 0; j < nj; ++j) {

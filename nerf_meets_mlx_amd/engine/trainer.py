@@ -94,21 +94,16 @@ class Trainer:
 
     # ---------------------------------------------------------------- rendering
     def render_rays(self, rays: torch.Tensor, u=None):
-        """render_rays_eval on packed rays, chunked like batchify_rays; returns rgb [B,3]."""
+        """render_rays_eval on packed rays, chunked like batchify_rays (`chunk` rays per call of the fused
+        renderer `nerf_render_rays_fused`); returns rgb [B,3]."""
         outs = []
         for s in range(0, rays.shape[0], self.chunk):
             r = rays[s:s + self.chunk]
-            z = sampling.sample_coarse(r, self.n)
-            raw = self.coarse.query(r, z, ref_quirks=self.q)
-            rgb, _, _, w, _ = render.composite(raw, z, r, 0.0, self.white_bkgd)
-            if self.N > 0:
-                uu = None if u is None else u[s:s + self.chunk]
-                if uu is None:
-                    uu = torch.rand(r.shape[0], self.N, device=self.device, generator=self.gen)
-                _, zf = sampling.importance_sample(z, w, self.N, u=uu)
-                raw = (self.fine or self.coarse).query(r, zf, ref_quirks=self.q)
-                rgb, _, _, _, _ = render.composite(raw, zf, r, 0.0, self.white_bkgd, need_weights=False)
-            outs.append(rgb)
+            uu = None if u is None else u[s:s + self.chunk]
+            if uu is None and self.N > 0:
+                uu = torch.rand(r.shape[0], self.N, device=self.device, generator=self.gen)
+            outs.append(render.render_rays_fused(r, self.coarse, self.fine, self.n, self.N, u=uu,
+                                                 white_bkgd=self.white_bkgd, ref_quirks=self.q, with_coarse=False)["rgb_map"])
         return torch.cat(outs, 0)
 
     def render_frame(self, c2w, shard: bool = True) -> Optional[torch.Tensor]:

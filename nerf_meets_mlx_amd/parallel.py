@@ -61,3 +61,33 @@ def gather_rows_to_rank0(local: torch.Tensor, total_rows: int):
     if rank != 0:
         return None
     return torch.cat([o[:hi - lo] for o, (lo, hi) in zip(out, sizes)], 0)
+
+
+class NativeComm:
+    """RCCL communicator owned by libnerf_hip (`nerf_comm_*`, `nerf_allreduce_grads`): the same all-reduce without
+    going through torch.distributed's process group.  The 128-byte id is created on rank 0 and handed to the other
+    ranks by the caller (here: a torch.distributed broadcast, any out-of-band channel works)."""
+
+    def __init__(self, rank: int, world_size: int, device="cuda"):
+        import ctypes as C
+        from . import _native as N
+        self._N, self._C = N, C
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            N.check(N.lib().nerf_comm_unique_id(ident))
+        if world_size > 1:
+            t = torch.tensor(list(ident.raw), dtype=torch.uint8, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t, src=0)
+            ident = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        self.comm = C.c_void_p()
+        N.check(N.lib().nerf_comm_init(C.byref(self.comm), world_size, rank, ident))
+
+    def allreduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
+        N = self._N
+        N.check(N.lib().nerf_allreduce_grads(self.comm, N.ptr(flat), flat.numel(), N.stream()))
+        return flat
+
+    def close(self):
+        if self.comm:
+            self._N.check(self._N.lib().nerf_comm_destroy(self.comm))
+            self.comm = self._C.c_void_p()

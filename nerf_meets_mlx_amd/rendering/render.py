@@ -44,6 +44,43 @@ def composite_backward(raw, z_vals, rays, d_rgb, white_bkgd=False, d_acc=None, d
     return d_raw
 
 
+_WS = {}
+
+
+def render_rays_fused(rays, network_coarse, network_fine, n_depth_samples, N_importance, u=None, white_bkgd=False,
+                      ref_quirks=True, with_coarse=True):
+    """render_rays_eval as ONE C call (`nerf_render_rays_fused`): same kernels, same results as the staged path."""
+    import ctypes as C
+    rays = N.f32(rays)
+    B, n, Nn = rays.shape[0], int(n_depth_samples), int(N_importance or 0)
+    dev = rays.device
+    if Nn > 0 and u is None:
+        u = torch.rand(B, Nn, dtype=torch.float32, device=dev)
+    nbytes = N.lib().nerf_render_workspace_bytes(B, n, Nn)
+    ws = _WS.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _WS[dev] = ws
+    f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    rgb, disp, acc = f(B, 3), f(B), f(B)
+    ret = {}
+    if with_coarse:
+        ret = {"rgb_coarse": f(B, 3), "disp_coarse": f(B), "acc_coarse": f(B), "z_vals": f(B, n), "weights": f(B, n)}
+    fine = network_fine if network_fine else network_coarse
+    N.check(N.lib().nerf_render_rays_fused(
+        C.byref(network_coarse.arch), N.ptr(network_coarse.packed()), N.ptr(fine.packed()), N.ptr(rays), B, n, Nn,
+        N.ptr(u) if Nn > 0 else None, 0 if ref_quirks else 1, int(bool(white_bkgd)), N.ptr(ws), N.ptr(rgb), N.ptr(disp),
+        N.ptr(acc), N.ptr(ret.get("rgb_coarse")), N.ptr(ret.get("disp_coarse")), N.ptr(ret.get("acc_coarse")),
+        N.ptr(ret.get("z_vals")), N.ptr(ret.get("weights")), N.stream()))
+    out = {"rgb_map": rgb, "disp_map": disp[:, None], "acc_map": acc[:, None]}
+    if with_coarse:
+        if Nn == 0:
+            ret["disp_coarse"], ret["acc_coarse"] = disp, acc
+        out.update({"rgb_coarse": ret["rgb_coarse"], "disp_coarse": ret["disp_coarse"][:, None],
+                    "acc_coarse": ret["acc_coarse"][:, None], "z_vals": ret["z_vals"], "weights": ret["weights"][..., None]})
+    return out
+
+
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None):
     """`rendering/render.py:20-96`: returns (rgb_map [B,3], disp_map [B,1], acc_map [B,1],
     weights [B,n,1], depth_map [B,1]) -- shapes as upstream."""

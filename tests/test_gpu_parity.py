@@ -577,3 +577,46 @@ def test_image_fitter_tracks_oracle_loop():
     assert losses[-1] < 0.5 * losses[0]
     pred = fit.predict()
     assert pred.shape == (H, W, 3) and torch.isfinite(pred).all()
+
+
+# ------------------------------------------------------------------------------ fused renderer entry point
+def test_render_rays_fused_equals_staged_path():
+    """nerf_render_rays_fused enqueues the same kernels as render_rays_eval: results must be bit-identical."""
+    from nerf_meets_mlx_amd.rendering import render
+    from nerf_meets_mlx_amd.models import NeRF as NM, embedding
+    mc, arch, fc = _model_pair(5, 1.5)
+    mf, _, ff = _model_pair(6, 1.5)
+    fp, _ = embedding.get_embedder(10); fd, _ = embedding.get_embedder(4)
+    q = NM.NetworkQuery(fp, fd, 65536)
+    B, n, Nn = 300, 64, 128
+    rays = _rays(B, 3).to(DEV)
+    u = torch.rand(B, Nn, device=DEV)
+    a = render.render_rays_eval(rays, mc, q, n, N_importance=Nn, network_fine=mf, white_bkgd=True, u=u)
+    b = render.render_rays_fused(rays, mc, mf, n, Nn, u=u, white_bkgd=True)
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb_coarse", "acc_coarse", "z_vals", "weights"):
+        assert torch.equal(a[k], b[k]), k
+    c = render.render_rays_fused(rays, mc, None, n, 0, white_bkgd=False)
+    d = render.render_rays(rays, mc, q, n, white_bkgd=False)
+    assert torch.equal(c["rgb_map"], d["rgb_map"]) and torch.equal(c["weights"], d["weights"])
+
+
+def test_native_rccl_allreduce_single_rank():
+    """nerf_comm_* / nerf_allreduce_grads (RCCL resolved lazily): a 1-rank communicator is the identity."""
+    from nerf_meets_mlx_amd import parallel
+    comm = parallel.NativeComm(0, 1, DEV)
+    g = torch.randn(595844, device=DEV)
+    want = g.clone()
+    comm.allreduce_sum_(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    comm.close()
+
+
+def test_headless_entrypoint_runs():
+    """entrypoints/__test_nerf.py:main without the GUI / file output: a few iterations on the synthetic scene."""
+    from nerf_meets_mlx_amd.entrypoints import test_nerf
+    res = test_nerf.main(None, max_iter=3, hw_synthetic=16, n_train_synthetic=2, render_every=3, n_render_poses=1,
+                         log_every=1)
+    assert len(res["losses"]) == 3 and all(np.isfinite(l[1]) and np.isfinite(l[2]) for l in res["losses"])
+    assert res["frames"][0].shape == (16, 16, 3) and res["video"][0].shape == (16, 16, 3)
+    assert res["trainer"].it == 3
