@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--train-images", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mlp-variant", type=int, default=0)
+    ap.add_argument("--n-importance", type=int, default=128, help="0 = coarse-only (BASELINE configs[1] with --hw 400)")
     args = ap.parse_args()
 
     from nerf_meets_mlx_amd import _native, parallel
@@ -60,7 +61,7 @@ def main():
     imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, args.train_images, seed=0, device=dev)
     # seed 4: both networks start with sigma > 0 (a net whose raw sigma starts negative everywhere has an exactly
     # zero gradient under the reference's formulas and never trains -- DESIGN.md section 8)
-    tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=128, seed=4, device=dev,
+    tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=args.n_importance, seed=4, device=dev,
                  chunk=args.render_rays)
     # render chunk of this rank: a contiguous slice of a render pose's pixel list, resident on the device
     lo, _ = parallel.shard_range(H * W, rank, world)
@@ -72,7 +73,7 @@ def main():
     def timed_fine_query(r, zf):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        raw = tr.fine.query(r, zf, ref_quirks=True)
+        raw = (tr.fine or tr.coarse).query(r, zf, ref_quirks=True)
         e1.record()
         ev["t"].append((e0, e1))
         return raw
@@ -80,28 +81,41 @@ def main():
     from nerf_meets_mlx_amd import sampling
     from nerf_meets_mlx_amd.rendering import render
 
+    NI = args.n_importance
+    n_fine = 64 + NI
+
     def render_chunk():
         z = sampling.sample_coarse(rrays, 64)
+        if NI == 0:
+            raw = timed_fine_query(rrays, z) if tr.fine is None else tr.coarse.query(rrays, z)
+            return render.composite(raw, z, rrays, 0.0, True, need_weights=False)[0]
         raw = tr.coarse.query(rrays, z)
         _, _, _, w, _ = render.composite(raw, z, rrays, 0.0, True)
-        u = torch.rand(rrays.shape[0], 128, device=dev, generator=tr.gen)
-        _, zf = sampling.importance_sample(z, w, 128, u=u)
+        u = torch.rand(rrays.shape[0], NI, device=dev, generator=tr.gen)
+        _, zf = sampling.importance_sample(z, w, NI, u=u)
         raw = timed_fine_query(rrays, zf)
         return render.composite(raw, zf, rrays, 0.0, True, need_weights=False)[0]
 
+    phase = {"train": [], "render": []}
+
     def step():
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
         out = tr.train_step()
+        e[1].record()
         rgb = render_chunk()
+        e[2].record()
+        phase["train"].append((e[0], e[1])); phase["render"].append((e[1], e[2]))
         return out, rgb
 
     def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        parallel.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    ev["t"].clear()
+    ev["t"].clear(); phase["train"].clear(); phase["render"].clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -118,7 +132,14 @@ def main():
     value = rays_per_step * args.steps / dt
     # dominant kernel: fused MLP forward over render_rays x 192 samples
     k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["t"]]))
-    flop = FLOP_PER_SAMPLE_FWD * args.render_rays * 192
+    flop = FLOP_PER_SAMPLE_FWD * args.render_rays * n_fine
+    # per-phase throughput (events on the launch stream) and algorithmic MFMA fractions (train = 3x forward
+    # FLOPs over 64 + n_fine samples, render = 1x; the repeated coarse forward of __test_nerf.py:270 is not credited)
+    t_train = float(np.mean([a.elapsed_time(b) for a, b in phase["train"]])) * 1e-3
+    t_render = float(np.mean([a.elapsed_time(b) for a, b in phase["render"]])) * 1e-3
+    spr = (64 + n_fine) if NI > 0 else 64
+    train_tf = 3 * FLOP_PER_SAMPLE_FWD * spr * args.n_rand / t_train / 1e12
+    render_tf = FLOP_PER_SAMPLE_FWD * spr * args.render_rays / t_render / 1e12
     achieved = flop / (k_ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
     # this same command, committed under profiles/); null when no measurement matches the workload
@@ -126,23 +147,26 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
             pm = json.load(fp)
-        if pm.get("samples_per_launch") == args.render_rays * 192:
+        if pm.get("samples_per_launch") == args.render_rays * n_fine:
             traffic = pm["hbm_bytes_per_launch"]
     except OSError:
         pass
     line = {
-        "metric": "train+render rays/sec on Lego 800x800 (synthetic), coarse+fine 64+128",
+        "metric": f"train+render rays/sec on Lego {H}x{W} (synthetic), " + (f"coarse+fine 64+{NI}" if NI > 0 else "coarse-only 64"),
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"configs[2]: Lego {H}x{W} coarse+fine NeRF (64+128 importance samples), "
-                               f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU",
+        "config": {"workload": (f"configs[2]: Lego {H}x{W} coarse+fine NeRF (64+{NI} importance samples), " if NI > 0 else
+                                f"configs[1]: Lego {H}x{W} coarse-only NeRF (64 samples/ray), ")
+                               + f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU",
                    "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
+        "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
+        "train_mfma_frac": train_tf / BF16_MFMA_PEAK_TFLOPS, "render_mfma_frac": render_tf / BF16_MFMA_PEAK_TFLOPS,
         "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
         "roofline": {"bound": "mfma", "kernel": "mlp_fwd_ring_kernel (render fine pass)", "achieved": achieved,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "algorithmic_bytes": args.render_rays * (192 * 20 + 44),
-                     "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * 192},
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
+                     "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * n_fine},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)

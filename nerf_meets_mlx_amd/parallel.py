@@ -24,10 +24,25 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        local = int(os.environ.get("NERF_FORCE_DEVICE", local))     # rehearsals: several ranks on one GPU (gloo)
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
-    return rank, ws, local
+            try:      # eager communicator on this rank's GPU (no lazy init inside the first collective)
+                dist.init_process_group(backend=backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))
+            except TypeError:
+                dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+    return rank, ws, int(os.environ.get("NERF_FORCE_DEVICE", local))
+
+
+def barrier():
+    """Process-group barrier (RCCL barriers are tied to the rank's device)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
