@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (loads torch's libamdhip64.so first so the HIP runtime is shared)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
+LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))   # override: A/B builds of the same ABI
 
 # every symbol of include/nerf_hip.h: name -> (restype, argtypes)
 _P, _I64, _I, _F, _U64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64

@@ -18,6 +18,11 @@
 #include "common.h"
 #include <string.h>
 
+// A/B switches (both default on): non-temporal DMA loads in the dW kernel / non-temporal fragment stores
+#ifndef NERF_NT_DW_LOADS
+#define NERF_NT_DW_LOADS 1
+#endif
+
 namespace nerf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -230,6 +235,17 @@ __device__ __forceinline__ void dma_frag_s(const void* gbase_uniform, unsigned l
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(lane_off), "s"(gbase_uniform), "s"(lds_addr) : "memory");
 }
+// non-temporal form for bytes that are read exactly once (the dW kernel's dZ / activation stream)
+__device__ __forceinline__ void dma_frag_nt(const void* gsrc_lane, unsigned lds_addr) {
+  unsigned keep;
+#if NERF_NT_DW_LOADS
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+#else
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+#endif
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
@@ -396,11 +412,21 @@ __device__ __forceinline__ bf16x8* frag_ptr(void* base, int64_t tile, int64_t st
   return reinterpret_cast<bf16x8*>(tb + slot * 1024 + (unsigned)(32 * r + 16 * h));
 }
 
+#ifndef NERF_NT_STORES
+#define NERF_NT_STORES 1
+#endif
+constexpr bool g_nt_stores = NERF_NT_STORES != 0;
+
 template <int COUNT>
 __device__ __forceinline__ void store_frags(void* base, int64_t tile, int64_t stride16, int slot0,
                                             const bf16x8 (&frags)[COUNT], int r, int h) {
+  // written once, read once by a later kernel: non-temporal, so that the 5 KB/sample store stream does not push the
+  // 2.4 MB weight stream (which every workgroup re-reads through the ring) out of L2
 #pragma unroll
-  for (int k = 0; k < COUNT; ++k) *frag_ptr(base, tile, stride16, slot0 + k, r, h) = frags[k];
+  for (int k = 0; k < COUNT; ++k) {
+    if (g_nt_stores) __builtin_nontemporal_store(frags[k], frag_ptr(base, tile, stride16, slot0 + k, r, h));
+    else *frag_ptr(base, tile, stride16, slot0 + k, r, h) = frags[k];
+  }
 }
 
 struct FwdArgs {
@@ -868,8 +894,8 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = wv + 8 * k;
-      if (i < jb.nf) dma_frag(dzp + (int64_t)tile * a.zstride + (jb.dz_slot + i) * 64, st + i * DW_FRAG_STRIDE);
-      else if (i < nfk) dma_frag(acp + (int64_t)tile * a.astride + (jb.act_slot + (i - jb.nf)) * 64,
+      if (i < jb.nf) dma_frag_nt(dzp + (int64_t)tile * a.zstride + (jb.dz_slot + i) * 64, st + i * DW_FRAG_STRIDE);
+      else if (i < nfk) dma_frag_nt(acp + (int64_t)tile * a.astride + (jb.act_slot + (i - jb.nf)) * 64,
                                  st + (nf_pad + i - jb.nf) * DW_FRAG_STRIDE);
       else dma_frag(dzp + (int64_t)tile * a.zstride + jb.dz_slot * 64, sink);      // padding: L2 hit, result unused
     }
