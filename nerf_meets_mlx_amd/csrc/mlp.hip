@@ -18,6 +18,9 @@
 #include "common.h"
 #include <string.h>
 
+#ifndef NERF_ABLATE
+#define NERF_ABLATE 0
+#endif
 // A/B switches (both default on): non-temporal DMA loads in the dW kernel / non-temporal fragment stores
 #ifndef NERF_NT_DW_LOADS
 #define NERF_NT_DW_LOADS 1
@@ -291,8 +294,14 @@ struct RingW {
   }
   __device__ __forceinline__ void boundary(int c, int lane) {
     ring_pos = (ring_pos + 1) & (RING_STAGES - 1);
+#if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
     issue((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1));
+#endif
     woff = ring_pos * RING_STAGE_BYTES + 16 * lane;
   }
   // fetch the group that starts at fragment fn (fn % RING_GROUP == 0) into nxt; crossing into a new chunk first
@@ -467,9 +476,16 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
       float p[3], d[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) { p[c] = rr[c] + zv * rr[3 + c]; d[c] = rr[8 + c]; }   // render.py:142
+#if NERF_ABLATE == 3          // timing-only build 3: no positional-encoding arithmetic
+      for (int q = 0; q < 4; ++q) for (int j = 0; j < 8; ++j) pe[t][q][j] = (__bf16)p[j % 3];
+      for (int q = 0; q < 2; ++q) for (int j = 0; j < 8; ++j) dpe[t][q][j] = (__bf16)d[j % 3];
+      if (false)
+#endif
+      {
       pe[t][0] = pe_frag<0, 63, 10>(p, a.fr.pos, h); pe[t][1] = pe_frag<1, 63, 10>(p, a.fr.pos, h);
       pe[t][2] = pe_frag<2, 63, 10>(p, a.fr.pos, h); pe[t][3] = pe_frag<3, 63, 10>(p, a.fr.pos, h);
       dpe[t][0] = pe_frag<0, 27, 4>(d, a.fr.dir, h); dpe[t][1] = pe_frag<1, 27, 4>(d, a.fr.dir, h);
+      }
     }
   }
 #define store(slot0, t, frags, count) \
