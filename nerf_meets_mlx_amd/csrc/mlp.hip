@@ -1351,8 +1351,9 @@ extern "C" int nerf_mlp_forward(const nerf_mlp_arch* arch, const void* packed, c
 extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
                                 int64_t B, int n, int freq_mode, float* raw, void* acts, void* stream) {
   NERF_ARCH_CHECK("nerf_query_fused");
-  NERF_REQUIRE(packed && rays && z && raw, NERF_E_NULL, "nerf_query_fused: NULL pointer");
   NERF_REQUIRE(n >= 1, NERF_E_SHAPE, "nerf_query_fused: n must be >= 1");
+  if (B <= 0) return NERF_OK;
+  NERF_REQUIRE(packed && rays && z && raw, NERF_E_NULL, "nerf_query_fused: NULL pointer");
   NERF_REQUIRE(freq_mode == 0 || freq_mode == 1, NERF_E_UNSUPPORTED, "nerf_query_fused: freq_mode must be 0 or 1");
   NERF_REQUIRE(B * (int64_t)n < (1ll << 31), NERF_E_SHAPE, "nerf_query_fused: B*n must be < 2^31 samples per call");
   if (B <= 0) return NERF_OK;

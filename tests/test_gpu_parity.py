@@ -615,8 +615,44 @@ def test_native_rccl_allreduce_single_rank():
 def test_headless_entrypoint_runs():
     """entrypoints/__test_nerf.py:main without the GUI / file output: a few iterations on the synthetic scene."""
     from nerf_meets_mlx_amd.entrypoints import test_nerf
-    res = test_nerf.main(None, max_iter=3, hw_synthetic=16, n_train_synthetic=2, render_every=3, n_render_poses=1,
+    res = test_nerf.main(None, max_iter=3, hw_synthetic=32, n_train_synthetic=2, render_every=3, n_render_poses=1,
                          log_every=1)
     assert len(res["losses"]) == 3 and all(np.isfinite(l[1]) and np.isfinite(l[2]) for l in res["losses"])
-    assert res["frames"][0].shape == (16, 16, 3) and res["video"][0].shape == (16, 16, 3)
+    assert res["frames"][0].shape == (32, 32, 3) and res["video"][0].shape == (32, 32, 3)
     assert res["trainer"].it == 3
+
+
+def test_streams_empty_and_ragged_inputs():
+    """Launches go to the caller's stream; empty batches are no-ops; ragged sizes (M % 32 != 0, B not a multiple of
+    the 8-tile super-tile) never touch memory outside their buffers (outputs compared with a padded run)."""
+    from nerf_meets_mlx_amd import sampling
+    from nerf_meets_mlx_amd.rendering import render
+    m, arch, flat = _model_pair(8, 1.5)
+    rays = _rays(77, 21).to(DEV)
+    z = sampling.sample_coarse(rays, 19)                                    # 1463 samples = 45.7 tiles
+    ref = m.query(rays, z)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        on_side = m.query(rays, z)
+        rgb_side = render.composite(on_side, z, rays, 0.0, True)[0]
+    s.synchronize()
+    assert torch.equal(on_side, ref)
+    assert torch.equal(rgb_side, render.composite(ref, z, rays, 0.0, True)[0])
+    # a prefix of the batch gives the prefix of the result (no cross-talk between tiles)
+    assert torch.equal(m.query(rays[:5].contiguous(), z[:5].contiguous()), ref[:5])
+    # empty batch
+    e = m.query(rays[:0].contiguous(), z[:0].contiguous())
+    assert e.shape == (0, 19, 4)
+    assert sampling.sample_coarse(rays[:0].contiguous(), 8).shape == (0, 8)
+    zn, zm = sampling.importance_sample(z[:0].contiguous(), torch.zeros(0, 19, device=DEV), 4, u=torch.zeros(0, 4, device=DEV))
+    assert zn.shape == (0, 4) and zm.shape == (0, 23)
+    # guard bytes around the outputs stay untouched
+    buf = torch.full((77 * 19 * 4 + 64,), 7.0, device=DEV)
+    out = buf[32:32 + 77 * 19 * 4].view(77, 19, 4)
+    import ctypes as C
+    from nerf_meets_mlx_amd import _native as N
+    N.check(N.lib().nerf_query_fused(C.byref(m.arch), N.ptr(m.packed()), N.ptr(rays), N.ptr(z), 77, 19, 0,
+                                     C.c_void_p(out.data_ptr()), None, N.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and bool((buf[:32] == 7.0).all()) and bool((buf[-32:] == 7.0).all())
