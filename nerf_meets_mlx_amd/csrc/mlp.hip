@@ -21,6 +21,11 @@
 #ifndef NERF_ABLATE
 #define NERF_ABLATE 0
 #endif
+// 1 = count the fragment stores of the last three chunk intervals into the ring's vmcnt wait (measured: no gain in
+// the training forward, and the backward chain spills with it: 2.7 -> 5.0 ms).  Kept as a negative result, off.
+#ifndef NERF_EXACT_VMCNT
+#define NERF_EXACT_VMCNT 0
+#endif
 // A/B switches (both default on): non-temporal DMA loads in the dW kernel / non-temporal fragment stores
 #ifndef NERF_NT_DW_LOADS
 #define NERF_NT_DW_LOADS 1
@@ -258,6 +263,7 @@ struct GlobalW {
   const bf16x8* __restrict__ wlane;    // stream base + lane
   const float* __restrict__ bias;
   __device__ __forceinline__ bf16x8 frag(int f, int) { return wlane[f * 64]; }
+  __device__ __forceinline__ void note_stores(int) {}
   __device__ __forceinline__ float4 bias4(int slot) { return *reinterpret_cast<const float4*>(bias + slot); }
 };
 
@@ -283,6 +289,7 @@ struct RingW {
   int ring_pos;                        // stage of the chunk the prefetch reads from
   int woff;                            // ring_pos * STAGE + 16 * lane
   bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
+  int st_cur, st_h1, st_h2;            // fragment stores issued in the current / previous two chunk intervals
 
   __device__ __forceinline__ void issue(int chunk, int stage) {
     const unsigned dst = lds0 + stage * RING_STAGE_BYTES;
@@ -297,7 +304,24 @@ struct RingW {
 #if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 #else
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // This chunk's DMAs were issued three boundaries ago.  Younger VMEM operations that may stay in flight: the 8
+    // DMAs of the next two chunks plus every activation / dZ store of the last three intervals (vmcnt retires in
+    // order and counts stores): waiting for fewer would stall the wave on HBM store latency at every boundary.
+    // Loads the compiler issues itself only make the true count larger, so this never under-waits.
+#if NERF_EXACT_VMCNT
+    const int allow = 8 + st_cur + st_h1 + st_h2;
+#else
+    const int allow = 8;
+#endif
+    if (allow >= 56)      asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (allow >= 48) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (allow >= 40) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (allow >= 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (allow >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (allow >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else                  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    st_h2 = st_h1; st_h1 = st_cur; st_cur = 0;
 #endif
 #if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
     issue((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1));
@@ -312,9 +336,15 @@ struct RingW {
     for (int i = 0; i < RING_GROUP; ++i)
       nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % RING_CHUNK) * 1024);
   }
+  __device__ __forceinline__ void note_stores(int k) { st_cur += k; }
+  // The counters restart at every pass (conservative: the first boundaries of a pass wait as if no store were in
+  // flight).  Inside the fully unrolled pass they are compile-time constants, so the `allow` ladder below folds to
+  // one s_waitcnt per boundary -- carried across passes it stayed a runtime 8-way branch that made hipcc spill.
+  __device__ __forceinline__ void new_pass() { st_cur = st_h1 = st_h2 = 0; }
   __device__ __forceinline__ void start(int lane) {
     ring_pos = RING_STAGES - 1;
     woff = 0;
+    st_cur = st_h1 = st_h2 = 0;
 #pragma unroll
     for (int c = 0; c < RING_STAGES - 1; ++c) issue(c, c);
     prefetch(0, lane);
@@ -489,7 +519,7 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
     }
   }
 #define store(slot0, t, frags, count) \
-  do { if (STORE) store_frags<count>(a.acts, tile0 + (t), a.astride, slot0, frags, r, h); } while (0)
+  do { if (STORE) { store_frags<count>(a.acts, tile0 + (t), a.astride, slot0, frags, r, h); ws.note_stores(count); } } while (0)
 #pragma unroll
   for (int t = 0; t < ST; ++t) { store(L::A_PE, t, pe[t], 4); store(L::A_DPE, t, dpe[t], 2); }
 
@@ -497,7 +527,7 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
   u32x4 mk[ST];
 #define MASK_BEGIN() do { _Pragma("unroll") for (int t = 0; t < ST; ++t) mk[t] = u32x4{0u, 0u, 0u, 0u}; } while (0)
 #define MASK_STORE(layer) do { if (STORE) { _Pragma("unroll") for (int t = 0; t < ST; ++t) \
-    *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0 + t, a.astride, L::A_MASK + (layer), r, h)) = mk[t]; } } while (0)
+    *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0 + t, a.astride, L::A_MASK + (layer), r, h)) = mk[t]; ws.note_stores(ST); } } while (0)
   MASK_BEGIN();
   layer_fwd<ST, 4, 8, true, STORE>(ws, L::F_L0, 0, pe, ha, mk, lane);
   MASK_STORE(0);
@@ -654,6 +684,7 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int ln = lane;
     asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
+    ws.new_pass();
     fwd_tiles<1, MODE, STORE>(a, ws, sp * 8 + wv, ntiles, ln);
   }
   ws.drain();                                           // the ring always runs 3 chunks ahead
@@ -747,7 +778,7 @@ __device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile
     for (int t = 0; t < ST; ++t)
       mk[l][t] = *reinterpret_cast<const u32x4*>(frag_ptr(const_cast<void*>(a.acts), tile[t], a.astride, L::A_MASK + l, r, h));
 #define store(slot0, t, frags, count) \
-  do { store_frags<count>(a.dz, tile0 + (t), a.zstride, slot0, frags, r, h); } while (0)
+  do { store_frags<count>(a.dz, tile0 + (t), a.zstride, slot0, frags, r, h); ws.note_stores(count); } while (0)
 #pragma unroll
   for (int t = 0; t < ST; ++t) { store(L::Z_RGB, t, zrgb[t], 1); store(L::Z_A, t, zal[t], 1); }
 
@@ -821,6 +852,7 @@ __global__ void __launch_bounds__(512, 2) mlp_bwd_ring_kernel(BwdArgs a) {
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    ws.new_pass();
     bwd_tiles<1>(a, ws, sp * 8 + wv, ntiles, ln);
     // the pass ends inside the last chunk (1100 = 34 * 32 + 12): nothing else to do, the next pass starts at a
     // chunk boundary again because fragment indices restart at 0
@@ -1076,14 +1108,14 @@ __device__ __forceinline__ void fwd_tiles_img(const ImgArgs& a, WS& ws, int64_t 
   bf16x8 xin[ST][3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) xin[0][ks] = row_frag(a.x + m * LI::CIN, ks, h, LI::CIN);
-  if (STORE) store_frags<3>(a.acts, tile0, a.astride, LI::A_X, xin[0], r, h);
+  if (STORE) { store_frags<3>(a.acts, tile0, a.astride, LI::A_X, xin[0], r, h); ws.note_stores(3); }
   bf16x8 ha[ST][16], hb[ST][16];
   u32x4 mk[ST];
 #define IMG_LAYER(KS, FB, BS, IN, OUT, LYR)                                                        \
   do { mk[0] = u32x4{0u, 0u, 0u, 0u};                                                              \
        layer_fwd<ST, KS, 8, true, STORE>(ws, FB, BS, IN, OUT, mk, lane);                           \
        if (STORE) { store_frags<16>(a.acts, tile0, a.astride, LI::A_H0 + 16 * (LYR), OUT[0], r, h); \
-                    *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0, a.astride, LI::A_MASK + (LYR), r, h)) = mk[0]; } } while (0)
+                    *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0, a.astride, LI::A_MASK + (LYR), r, h)) = mk[0]; ws.note_stores(17); } } while (0)
   IMG_LAYER(3, LI::F_L0, 0, xin, ha, 0);
   IMG_LAYER(16, LI::F_L1 + 0 * 128, 256, ha, hb, 1);
   IMG_LAYER(16, LI::F_L1 + 1 * 128, 512, hb, ha, 2);
@@ -1135,6 +1167,7 @@ __global__ void __launch_bounds__(512, 2) mlp_img_fwd_ring_kernel(ImgArgs a) {
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    ws.new_pass();
     fwd_tiles_img<STORE>(a, ws, sp * 8 + wv, ntiles, ln);
   }
   ws.drain();
@@ -1154,6 +1187,7 @@ __global__ void __launch_bounds__(512, 2) mlp_img_bwd_ring_kernel(ImgArgs a) {
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
+    ws.new_pass();
     const int r = lane & 31, h = lane >> 5;
     const int64_t tile0 = sp * 8 + wv;
     const int64_t tile = tile0 < ntiles ? tile0 : ntiles - 1;
@@ -1170,24 +1204,24 @@ __global__ void __launch_bounds__(512, 2) mlp_img_bwd_ring_kernel(ImgArgs a) {
 #pragma unroll
     for (int l = 0; l < 8; ++l)
       mk[l][0] = *reinterpret_cast<const u32x4*>(frag_ptr(a.acts, tile, a.astride, LI::A_MASK + l, r, h));
-    store_frags<1>(a.dz, tile0, a.zstride, LI::Z_OUT, zo[0], r, h);
+    store_frags<1>(a.dz, tile0, a.zstride, LI::Z_OUT, zo[0], r, h); ws.note_stores(1);
     bf16x8 za[ST][16], zb[ST][16];
     layer_bwd<ST, 1, 8, true>(ws, LI::B_OUT, zo, zb, mk[7], lane);                                  // dZ7
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 112, zb[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 112, zb[0], r, h); ws.note_stores(16);
     layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 0 * 128, zb, za, mk[6], lane);                        // dZ6
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 96, za[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 96, za[0], r, h); ws.note_stores(16);
     layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 1 * 128, za, zb, mk[5], lane);                        // dZ5
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 80, zb[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 80, zb[0], r, h); ws.note_stores(16);
     layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 2 * 128, zb, za, mk[4], lane);                        // dZ4
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 64, za[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 64, za[0], r, h); ws.note_stores(16);
     layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 3 * 128, za, zb, mk[3], lane);                        // dZ3
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 48, zb[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 48, zb[0], r, h); ws.note_stores(16);
     layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 4 * 128, zb, za, mk[2], lane);                        // dZ2
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 32, za[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 32, za[0], r, h); ws.note_stores(16);
     layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 5 * 128, za, zb, mk[1], lane);                        // dZ1
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 16, zb[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 16, zb[0], r, h); ws.note_stores(16);
     layer_bwd<ST, 16, 8, true>(ws, LI::B_L7 + 6 * 128, zb, za, mk[0], lane);                        // dZ0
-    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 0, za[0], r, h);
+    store_frags<16>(a.dz, tile0, a.zstride, LI::Z_L0 + 0, za[0], r, h); ws.note_stores(16);
   }
   ws.drain();
 }
