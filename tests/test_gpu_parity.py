@@ -656,3 +656,32 @@ def test_streams_empty_and_ragged_inputs():
                                      C.c_void_p(out.data_ptr()), None, N.stream()))
     torch.cuda.synchronize()
     assert torch.equal(out, ref) and bool((buf[:32] == 7.0).all()) and bool((buf[-32:] == 7.0).all())
+
+
+def test_render_rays_perturb_lindisp_and_noise_paths():
+    """The options the reference's train kwargs carry (perturb, raw_noise_std, lindisp, retraw) through render_rays."""
+    from nerf_meets_mlx_amd.rendering import render
+    from nerf_meets_mlx_amd.models import NeRF as NM, embedding
+    mc, arch, fc = _model_pair(9, 1.5)
+    fp, _ = embedding.get_embedder(10); fd, _ = embedding.get_embedder(4)
+    q = NM.NetworkQuery(fp, fd, 65536)
+    rays = _rays(40, 31).to(DEV)
+    torch.manual_seed(0)
+    base = render.render_rays(rays, mc, q, 32, white_bkgd=True, retraw=True)
+    assert base["raw"].shape == (40, 32, 4)
+    jit = render.render_rays(rays, mc, q, 32, white_bkgd=True, perturb=1.0)
+    z0, z1 = base["z_vals"], jit["z_vals"]
+    assert not torch.equal(z0, z1) and bool((z1[:, 1:] >= z1[:, :-1]).all())
+    mids = 0.5 * (z0[:, 1:] + z0[:, :-1])
+    assert bool((z1[:, 1:-1] >= mids[:, :-1] - 1e-5).all()) and bool((z1[:, 1:-1] <= mids[:, 1:] + 1e-5).all())
+    noisy = render.render_rays(rays, mc, q, 32, white_bkgd=True, raw_noise_std=1.0)
+    assert torch.isfinite(noisy["rgb_map"]).all() and not torch.equal(noisy["rgb_map"], base["rgb_map"])
+    ld = render.render_rays(rays, mc, q, 32, white_bkgd=True, lindisp=True)
+    assert float(ld["z_vals"][0, 0]) == 0.0                                   # literal formula, Q12
+    # oracle cross-check of the jittered pass with the same uniforms
+    from nerf_meets_mlx_amd import sampling
+    t = torch.rand(40, 32)
+    zg = sampling.sample_coarse(rays, 32, perturb=1.0, t_rand=t.to(DEV)).cpu()
+    r = rays.cpu()
+    want = O.add_noise_z(O.sample_z_uniform(r[:, 6:7], r[:, 7:8], 32), 1.0, t)
+    np.testing.assert_allclose(zg.numpy(), want.numpy(), atol=1e-6)
