@@ -76,9 +76,16 @@ class NeRF:
             tree["output_linear"] = views["output"]
         return tree
 
+    def trainable(self) -> torch.Tensor:
+        """The flat parameter buffer as an autograd leaf (for nerf_meets_mlx_amd.autograd); same storage as `params`."""
+        if not self.params.requires_grad:
+            self.params.requires_grad_(True)
+        return self.params
+
     def load_flat(self, flat: torch.Tensor):
         assert flat.numel() == self.n_params
-        self.params.copy_(flat.to(self.device, torch.float32).reshape(-1))
+        with torch.no_grad():
+            self.params.copy_(flat.to(self.device, torch.float32).reshape(-1))
         self._dirty = True
 
     def mark_updated(self):
