@@ -955,9 +955,11 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
 
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     const int rem = tile_hi - 1 - tile;                 // tiles issued after this one and still in flight (<= 2)
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0): this wave's transposed reads of the previous tile are complete before the barrier lets another
+    // wave's DMA refill that stage (hipcc may sink register-only MFMAs, and their waits, below an asm statement)
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // tile landed for every wave; stage (tile-1)%4 is free
     if (tile + DW_STAGES - 1 < tile_hi) issue(tile + DW_STAGES - 1, (tile - tile_lo + DW_STAGES - 1) % DW_STAGES);
     const char* st = smem + ((tile - tile_lo) % DW_STAGES) * DW_STAGE_BYTES;
