@@ -18,6 +18,9 @@
 #include "common.h"
 #include <string.h>
 
+#ifndef NERF_SPREAD_DMA
+#define NERF_SPREAD_DMA 1     // ring refill: one DMA per quarter chunk interval instead of a burst of 4
+#endif
 #ifndef NERF_ABLATE
 #define NERF_ABLATE 0
 #endif
@@ -66,7 +69,9 @@ constexpr int B_RGB = 0, B_DIR = 4, B_FA = 68, B_L7 = 204, B_L6 = 332, B_L5 = 46
 constexpr int B_TOTAL = 1100, B_PADDED = 1120;    // padded with zero fragments to whole 32-fragment ring chunks
 // fp32 bias slots
 constexpr int BI_FEAT = 2048, BI_ALPHA = 2304, BI_DIR = 2336, BI_RGB = 2464, BI_TOTAL = 2496;
-constexpr int64_t PACKED_BYTES = (int64_t)(F_TOTAL + B_PADDED) * 1024 + BI_TOTAL * 4;
+constexpr int F16_TOTAL = 1172, F16_PADDED = 1184;   // forward stream of the 16x16x32 variant (inference only)
+constexpr int64_t F16_OFFSET = (int64_t)(F_TOTAL + B_PADDED) * 1024 + BI_TOTAL * 4;    // appended after the bias slots
+constexpr int64_t PACKED_BYTES = F16_OFFSET + (int64_t)F16_PADDED * 1024;
 
 // activation store: fragment slots per 32-sample tile
 constexpr int A_PE = 0, A_DPE = 4, A_H0 = 6;       // H_l at A_H0 + 16 l, l = 0..7
@@ -291,14 +296,19 @@ struct RingW {
   bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
   int st_cur, st_h1, st_h2;            // fragment stores issued in the current / previous two chunk intervals
 
-  __device__ __forceinline__ void issue(int chunk, int stage) {
-    const unsigned dst = lds0 + stage * RING_STAGE_BYTES;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = wv + 8 * k;
-      dma_frag_s(wsrc + ((int64_t)chunk * RING_CHUNK + i) * 1024, lane16, dst + i * 1024);
-    }
+  // this wave's k-th (of 4) share of `chunk`: fragments wv, wv+8, wv+16, wv+24
+  __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
+    const int i = wv + 8 * k;
+    dma_frag_s(wsrc + ((int64_t)chunk * RING_CHUNK + i) * 1024, lane16, lds0 + stage * RING_STAGE_BYTES + i * 1024);
   }
+  __device__ __forceinline__ void issue(int chunk, int stage) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) issue_one(chunk, stage, k);
+  }
+  // Whole chunks refill their freed stage one DMA per quarter of the interval (a burst of 4 right behind the barrier
+  // stalls both waves of a SIMD on the VMEM issue path at once); the partial last chunk of a pass keeps the burst.
+  // (not in the activation-storing training forward, RING_GROUP 2: it is at the VGPR limit and HBM-bound anyway)
+  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && RING_GROUP == 4 && (c + 1) * RING_CHUNK <= TOTAL; }
   __device__ __forceinline__ void boundary(int c, int lane) {
     ring_pos = (ring_pos + 1) & (RING_STAGES - 1);
 #if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
@@ -324,7 +334,8 @@ struct RingW {
     st_h2 = st_h1; st_h1 = st_cur; st_cur = 0;
 #endif
 #if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
-    issue((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1));
+    if (spread(c)) issue_one((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1), 0);
+    else issue((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1));
 #endif
     woff = ring_pos * RING_STAGE_BYTES + 16 * lane;
   }
@@ -332,6 +343,11 @@ struct RingW {
   // runs the ring protocol for it (the previous chunk's last group is already in registers)
   __device__ __forceinline__ void prefetch(int fn, int lane) {
     if ((fn % RING_CHUNK) == 0) boundary(fn / RING_CHUNK, lane);
+#if NERF_ABLATE != 2
+    else if ((fn % (RING_CHUNK / 4)) == 0 && spread(fn / RING_CHUNK))
+      issue_one((fn / RING_CHUNK + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1),
+                (fn % RING_CHUNK) / (RING_CHUNK / 4));
+#endif
 #pragma unroll
     for (int i = 0; i < RING_GROUP; ++i)
       nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % RING_CHUNK) * 1024);
@@ -667,6 +683,20 @@ __device__ __forceinline__ void ring_load_bias(const float* __restrict__ bias, i
 // variant 3: persistent workgroups of 8 waves x 32 samples, weights through the shared LDS ring
 constexpr int F_CHUNKS = L::F_TOTAL / RING_CHUNK;     // 37
 static_assert(F_CHUNKS * RING_CHUNK == L::F_TOTAL, "forward stream must be whole chunks");
+
+#ifdef NERF_CLOCK_STAMP
+// Diagnostic build only (tools/probe_clock.py): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+// (MI355X_MICROARCH "DVFS" item 6).  Stamps go to a buffer of their own; no output depends on them.
+__device__ unsigned long long g_stamps[4096][4];
+#define NERF_STAMP_BEGIN() const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long st_passes = 0
+#define NERF_STAMP_PASS() ++st_passes
+#define NERF_STAMP_END() do { if (threadIdx.x == 0 && blockIdx.x < 4096) { g_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st_t0; \
+  g_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - st_r0; g_stamps[blockIdx.x][2] = st_passes; g_stamps[blockIdx.x][3] = 1; } } while (0)
+#else
+#define NERF_STAMP_BEGIN()
+#define NERF_STAMP_PASS()
+#define NERF_STAMP_END()
+#endif
 template <int MODE, bool STORE>
 __global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63;
@@ -681,13 +711,268 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
   ws.start(lane);
   ring_load_bias(a.bias, L::BI_TOTAL);
   __syncthreads();
+  NERF_STAMP_BEGIN();
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int ln = lane;
     asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
     ws.new_pass();
     fwd_tiles<1, MODE, STORE>(a, ws, sp * 8 + wv, ntiles, ln);
+    NERF_STAMP_PASS();
   }
+  NERF_STAMP_END();
   ws.drain();                                           // the ring always runs 3 chunks ahead
+}
+
+
+// ==========================================================================================
+// Variant 4 (inference only): the same register-resident chain on v_mfma_f32_16x16x32_bf16.
+// The guide measures a higher held clock for this shape (MI355X_MICROARCH "DVFS give-back" item 7).  A wave still
+// carries 32 samples, as two 16-sample column tiles that share every A fragment (16 output features x 32 k).
+// Accumulator: col = lane&15 (sample), row = 4 (lane>>4) + reg; two stacked 16-feature tiles give the next layer's
+// B fragment, element j of lane group g = feature 16 (j>>2) + 4 g + (j&3) of the 32-feature k-step.
+// ==========================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x2 pack2(float a, float b) {       // one v_cvt_pk_bf16_f32
+  const f32x2 v = {a, b};
+  return __builtin_convertvector(v, bf16x2);
+}
+__device__ __forceinline__ bf16x2 relu_pack(float a, float b) {
+  s16x2 q = __builtin_bit_cast(s16x2, pack2(a, b));
+  const s16x2 zero = {0, 0};
+  q = __builtin_elementwise_max(q, zero);
+  return __builtin_bit_cast(bf16x2, q);
+}
+namespace L16 {
+constexpr int F_L0 = 0, F_L1 = 32, F_L5 = 544, F_L6 = 704, F_L7 = 832, F_FA = 960, F_DIR = 1096, F_RGB = 1168;
+constexpr int CHUNKS = L::F16_PADDED / RING_CHUNK;     // 37
+}
+__host__ __device__ constexpr int kperm16(int ks, int g, int j) { return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3); }
+
+__device__ float fwd_src16(const float* __restrict__ p, int f, int i, int g, int j) {
+  if (f < L16::F_L1) {
+    const int nt = f / 2, kk = kperm16(f % 2, g, j);
+    return kk < 63 ? p[L::P_W0 + (16 * nt + i) * 63 + kk] : 0.0f;
+  }
+  if (f < L16::F_L5) {
+    const int q = f - L16::F_L1, l = 1 + q / 128, r = q % 128;
+    return p[L::pw(l) + (16 * (r / 8) + i) * 256 + kperm16(r % 8, g, j)];
+  }
+  if (f < L16::F_L6) {
+    const int q = f - L16::F_L5, n = 16 * (q / 10) + i, kk = kperm16(q % 10, g, j);
+    if (kk < 64) return kk < 63 ? p[L::P_W5 + n * 319 + kk] : 0.0f;
+    return p[L::P_W5 + n * 319 + 63 + (kk - 64)];
+  }
+  if (f < L16::F_FA) {
+    const int q = f - L16::F_L6, l = 6 + q / 128, r = q % 128;
+    return p[L::pw(l) + (16 * (r / 8) + i) * 256 + kperm16(r % 8, g, j)];
+  }
+  if (f < L16::F_DIR) {
+    const int q = f - L16::F_FA;
+    if (q < 128) return p[L::P_WF + (16 * (q / 8) + i) * 256 + kperm16(q % 8, g, j)];
+    return i == 0 ? p[L::P_WA + kperm16(q - 128, g, j)] : 0.0f;
+  }
+  if (f < L16::F_RGB) {
+    const int q = f - L16::F_DIR, n = 16 * (q / 9) + i, kk = kperm16(q % 9, g, j);
+    if (kk < 256) return p[L::P_WD + n * 283 + kk];
+    return (kk - 256) < 27 ? p[L::P_WD + n * 283 + kk] : 0.0f;
+  }
+  if (f < L::F16_TOTAL) return i < 3 ? p[L::P_WR + i * 128 + kperm16(f - L16::F_RGB, g, j)] : 0.0f;
+  return 0.0f;
+}
+
+__global__ void __launch_bounds__(256) pack16_kernel(const float* __restrict__ p, bf16x8* __restrict__ w16) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= L::F16_PADDED * 64) return;
+  const int f = t >> 6, lane = t & 63;
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (__bf16)fwd_src16(p, f, lane & 15, lane >> 4, j);
+  w16[t] = v;
+}
+
+// per-channel positional-encoding parameters in LDS (behind the bias slots): {freq, phase [rev], dim, kind}
+constexpr int PE16_OFF = RING_BIAS_OFF + 2560 * 4;               // 64 pos + 32 dir entries of 16 bytes
+constexpr int RING16_LDS_BYTES = PE16_OFF + 96 * 16;
+__device__ __forceinline__ void pe16_build(const PeFreq& fr) {
+  for (int c = threadIdx.x; c < 96; c += blockDim.x) {
+    const bool dir = c >= 64;
+    const Chan ch = chan_of(dir ? c - 64 : c, dir ? 27 : 63);
+    float4 e;
+    e.x = ch.kind == 1 || ch.kind == 2 ? (dir ? fr.dir[ch.band] : fr.pos[ch.band]) : 0.0f;
+    e.y = ch.kind == 2 ? 0.25f : 0.0f;
+    e.z = __int_as_float(ch.dim);
+    e.w = __int_as_float(ch.kind);
+    *reinterpret_cast<float4*>(ring_smem + PE16_OFF + 16 * c) = e;
+  }
+}
+__device__ __forceinline__ bf16x8 pe16_frag(const float (&x)[3], int c_base, int g, int table) {
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c_base + 16 * (j >> 2) + 4 * g + (j & 3);
+    const float4 e = *reinterpret_cast<const float4*>(ring_smem + PE16_OFF + 16 * (table + c));
+    const int dim = __float_as_int(e.z), kind = __float_as_int(e.w);
+    const float xv = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
+    const float t = __builtin_amdgcn_fractf((xv * e.x) * 0.15915494309189535f + e.y);
+    const float sv = __builtin_amdgcn_sinf(t);
+    v[j] = (__bf16)(kind == 0 ? xv : (kind == 3 ? 0.0f : sv));
+  }
+  return v;
+}
+
+// out[s][nt>>1] (elements 4 (nt&1) + i) = act( W[16-row tile nt] . in[s] + bias )
+template <int KS, int NT, bool RELU, class WS>
+__device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, const bf16x8 (&in)[2][KS],
+                                            bf16x8 (&out)[2][NT / 2], int lane) {
+  const int g = lane >> 4;
+  f32x4 prev[2];
+  // epilogue of a finished tile, run under the next tile's MFMAs.  The empty asm pins it there: without it hipcc
+  // reads the accumulators right behind their last MFMA (s_nop 6 in both waves of the SIMD at once).  ReLU after
+  // the bf16 rounding, as a packed 16-bit integer max on the bit patterns: one VALU op per two values.
+  auto finish = [&](int nt, f32x4 (&a)[2]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const bf16x2 pr = RELU ? relu_pack(a[s][i], a[s][i + 1]) : pack2(a[s][i], a[s][i + 1]);
+        out[s][nt >> 1][4 * (nt & 1) + i] = pr[0];
+        out[s][nt >> 1][4 * (nt & 1) + i + 1] = pr[1];
+      }
+  };
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float4 b = ws.bias4(bias_slot + 16 * nt + 4 * g);
+    f32x4 acc[2];
+    acc[0][0] = b.x; acc[0][1] = b.y; acc[0][2] = b.z; acc[0][3] = b.w;
+    acc[1] = acc[0];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 a = next_frag(ws, fbase + nt * KS + ks, lane);
+      if (nt > 0 && ks == KS / 2) finish(nt - 1, prev);      // previous tile's epilogue, half a tile of MFMAs later
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, in[0][ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, in[1][ks], acc[1], 0, 0, 0);
+    }
+    prev[0] = acc[0]; prev[1] = acc[1];
+  }
+  finish(NT - 1, prev);
+}
+
+__device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, RingW<L16::CHUNKS, L::F16_TOTAL, 4>& ws, int64_t tile0,
+                                            int64_t ntiles, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t tile = tile0 < ntiles ? tile0 : ntiles - 1;
+  bf16x8 pe[2][2], dpe[2][1];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    int64_t m = tile * 32 + 16 * s + c; if (m >= a.M) m = a.M - 1;
+    const int64_t ray = (int64_t)((unsigned)m / (unsigned)a.n);
+    const float* rr = a.rays + ray * NERF_RAY_STRIDE;
+    const float zv = a.z[m];
+    float p[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { p[k] = rr[k] + zv * rr[3 + k]; d[k] = rr[8 + k]; }
+#if NERF_ABLATE == 3          // timing-only build 3: no positional-encoding arithmetic
+    bf16x8 cst;
+    for (int j = 0; j < 8; ++j) cst[j] = (__bf16)(p[0] + d[0]);
+    pe[s][0] = cst; pe[s][1] = cst; dpe[s][0] = cst;
+#else
+    pe[s][0] = pe16_frag(p, 0, g, 0); pe[s][1] = pe16_frag(p, 32, g, 0);
+    dpe[s][0] = pe16_frag(d, 0, g, 64);
+#endif
+  }
+  bf16x8 ha[2][8], hb[2][8];
+  layer_fwd16<2, 16, true>(ws, L16::F_L0, 0, pe, ha, lane);
+  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 0 * 128, 256, ha, hb, lane);
+  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 1 * 128, 512, hb, ha, lane);
+  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 2 * 128, 768, ha, hb, lane);
+  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 3 * 128, 1024, hb, ha, lane);
+  {
+    bf16x8 cat[2][10];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      cat[s][0] = pe[s][0]; cat[s][1] = pe[s][1];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cat[s][2 + k] = ha[s][k];
+    }
+    layer_fwd16<10, 16, true>(ws, L16::F_L5, 1280, cat, hb, lane);
+  }
+  layer_fwd16<8, 16, true>(ws, L16::F_L6, 1536, hb, ha, lane);
+  layer_fwd16<8, 16, true>(ws, L16::F_L7, 1792, ha, hb, lane);
+  layer_fwd16<8, 16, false>(ws, L16::F_FA, L::BI_FEAT, hb, ha, lane);
+  float alpha[2];
+  {
+    const float4 b = ws.bias4(L::BI_ALPHA + 4 * g);
+    f32x4 acc[2];
+    acc[0][0] = b.x; acc[0][1] = b.y; acc[0][2] = b.z; acc[0][3] = b.w;
+    acc[1] = acc[0];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 wa = next_frag(ws, L16::F_FA + 128 + ks, lane);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb[0][ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb[1][ks], acc[1], 0, 0, 0);
+    }
+    alpha[0] = acc[0][0]; alpha[1] = acc[1][0];
+  }
+  bf16x8 hd[2][4];
+  {
+    bf16x8 cat[2][9];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cat[s][k] = ha[s][k];
+      cat[s][8] = dpe[s][0];
+    }
+    layer_fwd16<9, 8, true>(ws, L16::F_DIR, L::BI_DIR, cat, hd, lane);
+  }
+  {
+    const float4 b = ws.bias4(L::BI_RGB + 4 * g);
+    f32x4 acc[2];
+    acc[0][0] = b.x; acc[0][1] = b.y; acc[0][2] = b.z; acc[0][3] = b.w;
+    acc[1] = acc[0];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 wr = next_frag(ws, L16::F_RGB + ks, lane);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr, hd[0][ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr, hd[1][ks], acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int64_t m = tile0 * 32 + 16 * s + c;
+      if (g == 0 && tile0 < ntiles && m < a.M) {
+        float4 o; o.x = acc[s][0]; o.y = acc[s][1]; o.z = acc[s][2]; o.w = alpha[s];
+        *reinterpret_cast<float4*>(a.out + m * 4) = o;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512, 2) mlp_fwd_ring16_kernel(FwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ntiles = (a.M + 31) >> 5, nsuper = (ntiles + 7) >> 3;
+  RingW<L16::CHUNKS, L::F16_TOTAL, 4> ws;
+  ws.wsrc = reinterpret_cast<const char*>(a.wf);          // points at the 16x16x32 stream
+  ws.lane16 = 16 * lane;
+  ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
+  ws.wv = wv;
+  ws.start(lane);
+  ring_load_bias(a.bias, L::BI_TOTAL);
+  pe16_build(a.fr);
+  __syncthreads();
+  NERF_STAMP_BEGIN();
+  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    ws.new_pass();
+    fwd_tiles16(a, ws, sp * 8 + wv, ntiles, ln);
+    NERF_STAMP_PASS();
+  }
+  NERF_STAMP_END();
+  ws.drain();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1307,6 +1592,8 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
   float* bias = reinterpret_cast<float*>(base + (size_t)(L::F_TOTAL + L::B_PADDED) * 1024);
   const int total = (L::F_TOTAL + L::B_PADDED) * 64 + L::BI_TOTAL;
   hipLaunchKernelGGL(pack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), params, wf, wb, bias);
+  hipLaunchKernelGGL(pack16_kernel, dim3(L::F16_PADDED * 64 / 256), dim3(256), 0, as_stream(stream), params,
+                     reinterpret_cast<bf16x8*>(base + L::F16_OFFSET));
   return check_launch("nerf_mlp_pack");
 }
 
@@ -1327,7 +1614,17 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   const int64_t ntiles = (M + 31) / 32;
   auto s = as_stream(stream);
   const int variant = (g_mlp_variant == 0) ? (MODE == 1 ? 3 : 1) : g_mlp_variant;
-  if (variant == 3 && MODE == 1) {
+  if (variant == 4 && MODE == 1 && !acts) {
+    const int64_t nsuper = (ntiles + 7) / 8;
+    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
+    static bool once16 = false;
+    if (!once16) { ensure_lds(mlp_fwd_ring16_kernel, RING16_LDS_BYTES); once16 = true; }
+    FwdArgs a16 = a;
+    a16.wf = reinterpret_cast<const bf16x8*>(base + L::F16_OFFSET);
+    hipLaunchKernelGGL(mlp_fwd_ring16_kernel, g, b, RING16_LDS_BYTES, s, a16);
+    return check_launch("mlp forward (ring, 16x16x32)");
+  }
+  if ((variant == 3 || variant == 4) && MODE == 1) {
     const int64_t nsuper = (ntiles + 7) / 8;
     const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
     static bool once = false;
@@ -1477,7 +1774,7 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   b.wb = reinterpret_cast<const bf16x8*>(static_cast<const char*>(packed) + (size_t)L::F_TOTAL * 1024);
   b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz; b.astride = astride16(); b.zstride = zstride16();
   const int variant = g_mlp_variant == 0 ? 3 : g_mlp_variant;
-  if (variant == 3) {
+  if (variant >= 3) {
     const int64_t nsuper = (ntiles + 7) / 8;
     static bool once = false;
     if (!once) { ensure_lds(mlp_bwd_ring_kernel, RING_LDS_BYTES); once = true; }
@@ -1511,3 +1808,10 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   job(L::Z_RGB, 1, L::A_HD, 8, L::P_WR, 128, 0, 3, 128, L::P_BR);                                  // rgb
   return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astride16(), zstride16(), grads, s);
 }
+
+#ifdef NERF_CLOCK_STAMP
+extern "C" int nerf_debug_stamps(unsigned long long* host_out, int nwg) {
+  if (nwg > 4096) nwg = 4096;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nerf::g_stamps), (size_t)nwg * 32) == hipSuccess ? 0 : -4;
+}
+#endif

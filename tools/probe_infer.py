@@ -18,6 +18,13 @@ m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, 
 tag = os.path.basename(os.environ.get("NERF_HIP_LIB", "default"))
 B, n = 32768, 192
 r = rays(B); z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
-for rep in range(3):
-    ms = timeit(lambda: m.query(r, z))
-    print(f"[{tag}] fwd-infer B={B} n={n}: {ms:.3f} ms  {2*593408*B*n/ms/1e9:.0f} TFLOP/s", flush=True)
+from nerf_meets_mlx_amd import _native
+ref = None
+for variant in (3, 4, 3, 4):
+    _native.check(_native.lib().nerf_set_option(b"mlp_variant", variant))
+    out = m.query(r, z)
+    if ref is None: ref = out
+    else: print("max |v - v3| =", (out - ref).abs().max().item(), "rel", ((out - ref).norm() / ref.norm()).item())
+    for rep in range(2):
+        ms = timeit(lambda: m.query(r, z))
+        print(f"[{tag}] variant {variant} fwd-infer B={B} n={n}: {ms:.3f} ms  {2*593408*B*n/ms/1e9:.0f} TFLOP/s", flush=True)
