@@ -285,8 +285,9 @@ extern __shared__ __attribute__((aligned(16))) char ring_smem[];
 
 // RING_GROUP = fragments per software-pipeline group (one group in use, one in flight); TOTAL = fragments
 // consumed per pass (multiple of RING_GROUP)
-template <int NCHUNK, int TOTAL, int RING_GROUP = 4>
+template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8>
 struct RingW {
+  static constexpr int DPW = RING_CHUNK / NW;          // DMAs per wave per chunk
   const char* __restrict__ wsrc;       // global stream base (uniform)
   unsigned lane16;                     // 16 * lane
   unsigned lds0;                       // LDS byte address of ring_smem (M0 values are absolute)
@@ -296,14 +297,14 @@ struct RingW {
   bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
   int st_cur, st_h1, st_h2;            // fragment stores issued in the current / previous two chunk intervals
 
-  // this wave's k-th (of 4) share of `chunk`: fragments wv, wv+8, wv+16, wv+24
+  // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k
   __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
-    const int i = wv + 8 * k;
+    const int i = wv + NW * k;
     dma_frag_s(wsrc + ((int64_t)chunk * RING_CHUNK + i) * 1024, lane16, lds0 + stage * RING_STAGE_BYTES + i * 1024);
   }
   __device__ __forceinline__ void issue(int chunk, int stage) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) issue_one(chunk, stage, k);
+    for (int k = 0; k < DPW; ++k) issue_one(chunk, stage, k);
   }
   // Whole chunks refill their freed stage one DMA per quarter of the interval (a burst of 4 right behind the barrier
   // stalls both waves of a SIMD on the VMEM issue path at once); the partial last chunk of a pass keeps the burst.
@@ -314,6 +315,9 @@ struct RingW {
 #if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 #else
+    if (DPW == 8) {           // 4-wave workgroups: 8 DMAs per wave per chunk, two younger chunks stay in flight
+      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
     // This chunk's DMAs were issued three boundaries ago.  Younger VMEM operations that may stay in flight: the 8
     // DMAs of the next two chunks plus every activation / dZ store of the last three intervals (vmcnt retires in
     // order and counts stores): waiting for fewer would stall the wave on HBM store latency at every boundary.
@@ -331,6 +335,7 @@ struct RingW {
     else if (allow >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else                  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     st_h2 = st_h1; st_h1 = st_cur; st_cur = 0;
 #endif
 #if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
@@ -344,9 +349,9 @@ struct RingW {
   __device__ __forceinline__ void prefetch(int fn, int lane) {
     if ((fn % RING_CHUNK) == 0) boundary(fn / RING_CHUNK, lane);
 #if NERF_ABLATE != 2
-    else if ((fn % (RING_CHUNK / 4)) == 0 && spread(fn / RING_CHUNK))
+    else if ((fn % (RING_CHUNK / DPW)) == 0 && spread(fn / RING_CHUNK))
       issue_one((fn / RING_CHUNK + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1),
-                (fn % RING_CHUNK) / (RING_CHUNK / 4));
+                (fn % RING_CHUNK) / (RING_CHUNK / DPW));
 #endif
 #pragma unroll
     for (int i = 0; i < RING_GROUP; ++i)
@@ -381,7 +386,7 @@ struct RingW {
 };
 
 template <class WS> struct is_ring { static constexpr bool value = false; };
-template <int N, int T, int G> struct is_ring<RingW<N, T, G>> { static constexpr bool value = true; };
+template <int N, int T, int G, int W> struct is_ring<RingW<N, T, G, W>> { static constexpr bool value = true; };
 
 template <class WS>
 __device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }
@@ -823,19 +828,20 @@ __device__ __forceinline__ bf16x8 pe16_frag(const float (&x)[3], int c_base, int
   return v;
 }
 
-// out[s][nt>>1] (elements 4 (nt&1) + i) = act( W[16-row tile nt] . in[s] + bias )
-template <int KS, int NT, bool RELU, class WS>
-__device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, const bf16x8 (&in)[2][KS],
-                                            bf16x8 (&out)[2][NT / 2], int lane) {
+// out[s][nt>>1] (elements 4 (nt&1) + i) = act( W[16-row tile nt] . in[s] + bias ), s = 0..NS-1 sample tiles of 16
+template <int NS, int KS, int NT, bool RELU, class WS>
+__device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, const bf16x8 (&in)[NS][KS],
+                                            bf16x8 (&out)[NS][NT / 2], int lane) {
   const int g = lane >> 4;
-  f32x4 prev[2];
+  f32x4 prev[NS];
   // epilogue of a finished tile, run under the next tile's MFMAs.  The empty asm pins it there: without it hipcc
   // reads the accumulators right behind their last MFMA (s_nop 6 in both waves of the SIMD at once).  ReLU after
   // the bf16 rounding, as a packed 16-bit integer max on the bit patterns: one VALU op per two values.
-  auto finish = [&](int nt, f32x4 (&a)[2]) {
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+  auto finish = [&](int nt, f32x4 (&a)[NS]) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(a[s]));
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int i = 0; i < 4; i += 2) {
         const bf16x2 pr = RELU ? relu_pack(a[s][i], a[s][i + 1]) : pack2(a[s][i], a[s][i + 1]);
@@ -846,29 +852,32 @@ __device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, co
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const float4 b = ws.bias4(bias_slot + 16 * nt + 4 * g);
-    f32x4 acc[2];
+    f32x4 acc[NS];
     acc[0][0] = b.x; acc[0][1] = b.y; acc[0][2] = b.z; acc[0][3] = b.w;
-    acc[1] = acc[0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) acc[s] = acc[0];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bf16x8 a = next_frag(ws, fbase + nt * KS + ks, lane);
       if (nt > 0 && ks == KS / 2) finish(nt - 1, prev);      // previous tile's epilogue, half a tile of MFMAs later
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, in[0][ks], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, in[1][ks], acc[1], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, in[s][ks], acc[s], 0, 0, 0);
     }
-    prev[0] = acc[0]; prev[1] = acc[1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) prev[s] = acc[s];
   }
   finish(NT - 1, prev);
 }
 
-__device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, RingW<L16::CHUNKS, L::F16_TOTAL, 4>& ws, int64_t tile0,
-                                            int64_t ntiles, int lane) {
+// one wave: NS x 16 samples starting at sample wtile * 16 NS
+template <int NS, class WS>
+__device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wtile0, int64_t nwtiles, int lane) {
   const int c = lane & 15, g = lane >> 4;
-  const int64_t tile = tile0 < ntiles ? tile0 : ntiles - 1;
-  bf16x8 pe[2][2], dpe[2][1];
+  const int64_t wtile = wtile0 < nwtiles ? wtile0 : nwtiles - 1;
+  bf16x8 pe[NS][2], dpe[NS][1];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    int64_t m = tile * 32 + 16 * s + c; if (m >= a.M) m = a.M - 1;
+  for (int s = 0; s < NS; ++s) {
+    int64_t m = wtile * (16 * NS) + 16 * s + c; if (m >= a.M) m = a.M - 1;
     const int64_t ray = (int64_t)((unsigned)m / (unsigned)a.n);
     const float* rr = a.rays + ray * NERF_RAY_STRIDE;
     const float zv = a.z[m];
@@ -884,65 +893,68 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, RingW<L16::CHUNKS,
     dpe[s][0] = pe16_frag(d, 0, g, 64);
 #endif
   }
-  bf16x8 ha[2][8], hb[2][8];
-  layer_fwd16<2, 16, true>(ws, L16::F_L0, 0, pe, ha, lane);
-  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 0 * 128, 256, ha, hb, lane);
-  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 1 * 128, 512, hb, ha, lane);
-  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 2 * 128, 768, ha, hb, lane);
-  layer_fwd16<8, 16, true>(ws, L16::F_L1 + 3 * 128, 1024, hb, ha, lane);
+  bf16x8 ha[NS][8], hb[NS][8];
+  layer_fwd16<NS, 2, 16, true>(ws, L16::F_L0, 0, pe, ha, lane);
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L1 + 0 * 128, 256, ha, hb, lane);
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L1 + 1 * 128, 512, hb, ha, lane);
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L1 + 2 * 128, 768, ha, hb, lane);
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L1 + 3 * 128, 1024, hb, ha, lane);
   {
-    bf16x8 cat[2][10];
+    bf16x8 cat[NS][10];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
       cat[s][0] = pe[s][0]; cat[s][1] = pe[s][1];
 #pragma unroll
       for (int k = 0; k < 8; ++k) cat[s][2 + k] = ha[s][k];
     }
-    layer_fwd16<10, 16, true>(ws, L16::F_L5, 1280, cat, hb, lane);
+    layer_fwd16<NS, 10, 16, true>(ws, L16::F_L5, 1280, cat, hb, lane);
   }
-  layer_fwd16<8, 16, true>(ws, L16::F_L6, 1536, hb, ha, lane);
-  layer_fwd16<8, 16, true>(ws, L16::F_L7, 1792, ha, hb, lane);
-  layer_fwd16<8, 16, false>(ws, L16::F_FA, L::BI_FEAT, hb, ha, lane);
-  float alpha[2];
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L6, 1536, hb, ha, lane);
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L7, 1792, ha, hb, lane);
+  layer_fwd16<NS, 8, 16, false>(ws, L16::F_FA, L::BI_FEAT, hb, ha, lane);
+  float alpha[NS];
   {
     const float4 b = ws.bias4(L::BI_ALPHA + 4 * g);
-    f32x4 acc[2];
+    f32x4 acc[NS];
     acc[0][0] = b.x; acc[0][1] = b.y; acc[0][2] = b.z; acc[0][3] = b.w;
-    acc[1] = acc[0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) acc[s] = acc[0];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const bf16x8 wa = next_frag(ws, L16::F_FA + 128 + ks, lane);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb[0][ks], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb[1][ks], acc[1], 0, 0, 0);
-    }
-    alpha[0] = acc[0][0]; alpha[1] = acc[1][0];
-  }
-  bf16x8 hd[2][4];
-  {
-    bf16x8 cat[2][9];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, hb[s][ks], acc[s], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) alpha[s] = acc[s][0];
+  }
+  bf16x8 hd[NS][4];
+  {
+    bf16x8 cat[NS][9];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) cat[s][k] = ha[s][k];
       cat[s][8] = dpe[s][0];
     }
-    layer_fwd16<9, 8, true>(ws, L16::F_DIR, L::BI_DIR, cat, hd, lane);
+    layer_fwd16<NS, 9, 8, true>(ws, L16::F_DIR, L::BI_DIR, cat, hd, lane);
   }
   {
     const float4 b = ws.bias4(L::BI_RGB + 4 * g);
-    f32x4 acc[2];
+    f32x4 acc[NS];
     acc[0][0] = b.x; acc[0][1] = b.y; acc[0][2] = b.z; acc[0][3] = b.w;
-    acc[1] = acc[0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) acc[s] = acc[0];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 wr = next_frag(ws, L16::F_RGB + ks, lane);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr, hd[0][ks], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr, hd[1][ks], acc[1], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr, hd[s][ks], acc[s], 0, 0, 0);
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int64_t m = tile0 * 32 + 16 * s + c;
-      if (g == 0 && tile0 < ntiles && m < a.M) {
+    for (int s = 0; s < NS; ++s) {
+      const int64_t m = wtile0 * (16 * NS) + 16 * s + c;
+      if (g == 0 && wtile0 < nwtiles && m < a.M) {
         float4 o; o.x = acc[s][0]; o.y = acc[s][1]; o.z = acc[s][2]; o.w = alpha[s];
         *reinterpret_cast<float4*>(a.out + m * 4) = o;
       }
@@ -950,11 +962,14 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, RingW<L16::CHUNKS,
   }
 }
 
-__global__ void __launch_bounds__(512, 2) mlp_fwd_ring16_kernel(FwdArgs a) {
+// NW waves x NS sample tiles of 16 = 256 samples per workgroup pass either way: <8, 2> two waves per SIMD at 256
+// registers each; <4, 4> one wave per SIMD with the whole 512-register file, half the LDS fragment reads per FLOP.
+template <int NW, int NS>
+__global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t ntiles = (a.M + 31) >> 5, nsuper = (ntiles + 7) >> 3;
-  RingW<L16::CHUNKS, L::F16_TOTAL, 4> ws;
+  const int64_t nwtiles = (a.M + 16 * NS - 1) / (16 * NS), nsuper = (nwtiles + NW - 1) / NW;
+  RingW<L16::CHUNKS, L::F16_TOTAL, 4, NW> ws;
   ws.wsrc = reinterpret_cast<const char*>(a.wf);          // points at the 16x16x32 stream
   ws.lane16 = 16 * lane;
   ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
@@ -968,7 +983,7 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_ring16_kernel(FwdArgs a) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     ws.new_pass();
-    fwd_tiles16(a, ws, sp * 8 + wv, ntiles, ln);
+    fwd_tiles16<NS>(a, ws, sp * NW + wv, nwtiles, ln);
     NERF_STAMP_PASS();
   }
   NERF_STAMP_END();
@@ -1517,7 +1532,8 @@ static int g_dw_wgs = 0;       // 0: automatic (see launch_dw)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
 static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
 static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad16; }
-static int g_mlp_variant = 0;   // 0: auto (= 3), 1: ST=1 via L1, 2: ST=2 via L1, 3: LDS ring, 8 waves x 32 samples
+static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: LDS ring, 8 waves x 32 samples, 32x32x16 MFMA,
+                                // 4: ring, 16x16x32 MFMA, 8 waves x 32 samples (inference only), 5: same, 4 waves x 64 samples
 static int g_ring_wgs = 256;     // persistent workgroups of the ring kernels (one per CU)
 
 template <class K>
@@ -1613,18 +1629,24 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   fill_freqs(a.fr, freq_mode);
   const int64_t ntiles = (M + 31) / 32;
   auto s = as_stream(stream);
+  // auto: fused query -> LDS ring on 32x32x16.  The 16x16x32 variants (4, 5) hold a higher clock and win back-to-back
+  // on random data (+3 %), but inside the train+render step of bench.py variant 3 is 4 % faster
   const int variant = (g_mlp_variant == 0) ? (MODE == 1 ? 3 : 1) : g_mlp_variant;
-  if (variant == 4 && MODE == 1 && !acts) {
-    const int64_t nsuper = (ntiles + 7) / 8;
-    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
+  if ((variant == 4 || variant == 5) && MODE == 1 && !acts) {
+    const int64_t nsuper = (M + 255) / 256;
+    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs));
     static bool once16 = false;
-    if (!once16) { ensure_lds(mlp_fwd_ring16_kernel, RING16_LDS_BYTES); once16 = true; }
+    if (!once16) {
+      ensure_lds(mlp_fwd_ring16_kernel<8, 2>, RING16_LDS_BYTES); ensure_lds(mlp_fwd_ring16_kernel<4, 4>, RING16_LDS_BYTES);
+      once16 = true;
+    }
     FwdArgs a16 = a;
     a16.wf = reinterpret_cast<const bf16x8*>(base + L::F16_OFFSET);
-    hipLaunchKernelGGL(mlp_fwd_ring16_kernel, g, b, RING16_LDS_BYTES, s, a16);
+    if (variant == 4) hipLaunchKernelGGL((mlp_fwd_ring16_kernel<8, 2>), g, dim3(512), RING16_LDS_BYTES, s, a16);
+    else hipLaunchKernelGGL((mlp_fwd_ring16_kernel<4, 4>), g, dim3(256), RING16_LDS_BYTES, s, a16);
     return check_launch("mlp forward (ring, 16x16x32)");
   }
-  if ((variant == 3 || variant == 4) && MODE == 1) {
+  if (variant >= 3 && MODE == 1) {
     const int64_t nsuper = (ntiles + 7) / 8;
     const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
     static bool once = false;

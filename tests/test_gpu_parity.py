@@ -336,7 +336,7 @@ def _rays(B, seed):
     return O.pack_rays(o, d, 2.0, 6.0)
 
 
-@pytest.mark.parametrize("variant,quirk", [(1, True), (2, True), (2, False), (3, True), (3, False), (4, True), (4, False)])
+@pytest.mark.parametrize("variant,quirk", [(1, True), (2, True), (2, False), (3, True), (3, False), (4, True), (4, False), (5, True), (5, False)])
 def test_fused_query_matches_oracle(variant, quirk):
     from nerf_meets_mlx_amd import _native
     _native.check(_native.lib().nerf_set_option(b"mlp_variant", variant))

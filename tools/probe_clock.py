@@ -23,7 +23,7 @@ r[:, 8:] = d / d.norm(dim=-1, keepdim=True)
 z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
 m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0)
 m.load_flat(m.params * 1.5)          # O(1) activations through all layers: random, non-trivial MFMA operands
-for variant, mfma_per_wave, cyc in ((3, 1159, 32), (4, 1172 * 2, 16)):
+for variant, mfma_per_wave, cyc, wps in ((3, 1159, 32, 2), (4, 1172 * 2, 16, 2), (5, 1172 * 4, 16, 1)):
     _native.check(lib.nerf_set_option(b"mlp_variant", variant))
     t0 = time.time()
     while time.time() - t0 < 2.5:
@@ -39,7 +39,7 @@ for variant, mfma_per_wave, cyc in ((3, 1159, 32), (4, 1172 * 2, 16)):
     ghz = st[:, 0] / st[:, 1] * 0.1
     cyc_per_pass = st[:, 0] / st[:, 2]
     # per SIMD: 2 waves, each issuing mfma_per_wave MFMAs of `cyc` cycles per pass (8 tiles of 32 samples per WG)
-    busy = 2 * mfma_per_wave * cyc
+    busy = wps * mfma_per_wave * cyc
     print(f"variant {variant}: {ms:.3f} ms {2*593408*B*n/ms/1e9:.0f} TFLOP/s | in-kernel clock median {np.median(ghz):.3f} GHz "
           f"(min {ghz.min():.3f} max {ghz.max():.3f}) | cycles/pass median {np.median(cyc_per_pass):.0f}, MFMA-busy {busy} "
           f"= {busy/np.median(cyc_per_pass)*100:.1f} % of cycles | peak at this clock "

@@ -20,7 +20,7 @@ B, n = 32768, 192
 r = rays(B); z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
 from nerf_meets_mlx_amd import _native
 ref = None
-for variant in (3, 4, 3, 4):
+for variant in (3, 4, 5, 3, 4, 5):
     _native.check(_native.lib().nerf_set_option(b"mlp_variant", variant))
     out = m.query(r, z)
     if ref is None: ref = out
