@@ -205,8 +205,8 @@ int nerf_allreduce_grads(void* comm, float* grads, int64_t count, void* stream);
 int nerf_comm_destroy(void* comm);
 
 /* runtime selection of kernel variants (for A/B measurement):
- *   "mlp_variant"     0 auto (= 3) | 1,2 weights via L1 (32 / 64 samples per wave) | 3 LDS ring, 32x32x16 MFMA |
- *                     4 LDS ring, 16x16x32 MFMA, 8 waves x 32 samples (render path only) |
+ *   "mlp_variant"     0 auto | 1,2 weights via L1 (32 / 64 samples per wave) | 3 LDS ring, 32x32x16 MFMA |
+ *                     4 LDS ring, 16x16x32 MFMA, 8 waves x 32 samples (render path only; auto picks it there) |
  *                     5 same with 4 waves x 64 samples.  Training kernels use 3 for every value >= 3.
  *   "ring_workgroups" persistent workgroups of the ring kernels (default 256 = one per CU)
  *   "dw_workgroups"   0 auto | workgroups of the weight-gradient kernel                       */

@@ -361,7 +361,12 @@ struct RingW {
   // The counters restart at every pass (conservative: the first boundaries of a pass wait as if no store were in
   // flight).  Inside the fully unrolled pass they are compile-time constants, so the `allow` ladder below folds to
   // one s_waitcnt per boundary -- carried across passes it stayed a runtime 8-way branch that made hipcc spill.
-  __device__ __forceinline__ void new_pass() { st_cur = st_h1 = st_h2 = 0; }
+  __device__ __forceinline__ void new_pass() {
+    st_cur = st_h1 = st_h2 = 0;
+    // the ~1200 chunk/fragment source addresses are loop-invariant; hoisted, they no longer fit the SGPR file and
+    // are parked in VGPR lanes (v_writelane / v_readlane per DMA).  Opaque base per pass: two s_add per DMA instead.
+    asm volatile("" : "+s"(wsrc));
+  }
   __device__ __forceinline__ void start(int lane) {
     ring_pos = RING_STAGES - 1;
     woff = 0;
@@ -755,20 +760,36 @@ constexpr int F_L0 = 0, F_L1 = 32, F_L5 = 544, F_L6 = 704, F_L7 = 832, F_FA = 96
 constexpr int CHUNKS = L::F16_PADDED / RING_CHUNK;     // 37
 }
 __host__ __device__ constexpr int kperm16(int ks, int g, int j) { return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3); }
+// Which embedding channel sits in element j of lane group g in the encoding k-steps.  The order is ours to choose
+// (the packed weights follow it), so it is chosen to make the per-element (sin | cos, x | y | z) pattern the same in
+// all four lane groups -- only the frequency differs, three per-lane registers -- instead of a table lookup and four
+// selects per element.  Position (63 channels, 2 k-steps = slots 8 ks + j): slots 0-11 = bands 2g, 2g+1 as
+// (sin xyz, cos xyz); slots 12-14 = band 8 + (g>>1), sin for even g / cos for odd g, xyz; slot 15 = identity
+// channel g (zero pad for g = 3).  Direction (27 channels, 1 k-step): j 0-5 = band g, j 6 = identity g, j 7 = pad.
+__host__ __device__ constexpr int pos_chan16(int ks, int g, int j) {
+  const int sl = 8 * ks + j;
+  if (sl < 12) return 3 + 6 * (2 * g + sl / 6) + (sl % 6);
+  if (sl < 15) return 3 + 6 * (8 + (g >> 1)) + 3 * (g & 1) + (sl - 12);
+  return g < 3 ? g : -1;
+}
+__host__ __device__ constexpr int dir_chan16(int g, int j) {
+  if (j < 6) return 3 + 6 * g + j;
+  return (j == 6 && g < 3) ? g : -1;
+}
 
 __device__ float fwd_src16(const float* __restrict__ p, int f, int i, int g, int j) {
   if (f < L16::F_L1) {
-    const int nt = f / 2, kk = kperm16(f % 2, g, j);
-    return kk < 63 ? p[L::P_W0 + (16 * nt + i) * 63 + kk] : 0.0f;
+    const int nt = f / 2, ch = pos_chan16(f % 2, g, j);
+    return ch >= 0 ? p[L::P_W0 + (16 * nt + i) * 63 + ch] : 0.0f;
   }
   if (f < L16::F_L5) {
     const int q = f - L16::F_L1, l = 1 + q / 128, r = q % 128;
     return p[L::pw(l) + (16 * (r / 8) + i) * 256 + kperm16(r % 8, g, j)];
   }
   if (f < L16::F_L6) {
-    const int q = f - L16::F_L5, n = 16 * (q / 10) + i, kk = kperm16(q % 10, g, j);
-    if (kk < 64) return kk < 63 ? p[L::P_W5 + n * 319 + kk] : 0.0f;
-    return p[L::P_W5 + n * 319 + 63 + (kk - 64)];
+    const int q = f - L16::F_L5, n = 16 * (q / 10) + i, ks = q % 10;
+    if (ks < 2) { const int ch = pos_chan16(ks, g, j); return ch >= 0 ? p[L::P_W5 + n * 319 + ch] : 0.0f; }
+    return p[L::P_W5 + n * 319 + 63 + kperm16(ks - 2, g, j)];
   }
   if (f < L16::F_FA) {
     const int q = f - L16::F_L6, l = 6 + q / 128, r = q % 128;
@@ -780,9 +801,10 @@ __device__ float fwd_src16(const float* __restrict__ p, int f, int i, int g, int
     return i == 0 ? p[L::P_WA + kperm16(q - 128, g, j)] : 0.0f;
   }
   if (f < L16::F_RGB) {
-    const int q = f - L16::F_DIR, n = 16 * (q / 9) + i, kk = kperm16(q % 9, g, j);
-    if (kk < 256) return p[L::P_WD + n * 283 + kk];
-    return (kk - 256) < 27 ? p[L::P_WD + n * 283 + kk] : 0.0f;
+    const int q = f - L16::F_DIR, n = 16 * (q / 9) + i, ks = q % 9;
+    if (ks < 8) return p[L::P_WD + n * 283 + kperm16(ks, g, j)];
+    const int ch = dir_chan16(g, j);
+    return ch >= 0 ? p[L::P_WD + n * 283 + 256 + ch] : 0.0f;
   }
   if (f < L::F16_TOTAL) return i < 3 ? p[L::P_WR + i * 128 + kperm16(f - L16::F_RGB, g, j)] : 0.0f;
   return 0.0f;
@@ -798,34 +820,50 @@ __global__ void __launch_bounds__(256) pack16_kernel(const float* __restrict__ p
   w16[t] = v;
 }
 
-// per-channel positional-encoding parameters in LDS (behind the bias slots): {freq, phase [rev], dim, kind}
-constexpr int PE16_OFF = RING_BIAS_OFF + 2560 * 4;               // 64 pos + 32 dir entries of 16 bytes
-constexpr int RING16_LDS_BYTES = PE16_OFF + 96 * 16;
-__device__ __forceinline__ void pe16_build(const PeFreq& fr) {
-  for (int c = threadIdx.x; c < 96; c += blockDim.x) {
-    const bool dir = c >= 64;
-    const Chan ch = chan_of(dir ? c - 64 : c, dir ? 27 : 63);
-    float4 e;
-    e.x = ch.kind == 1 || ch.kind == 2 ? (dir ? fr.dir[ch.band] : fr.pos[ch.band]) : 0.0f;
-    e.y = ch.kind == 2 ? 0.25f : 0.0f;
-    e.z = __int_as_float(ch.dim);
-    e.w = __int_as_float(ch.kind);
-    *reinterpret_cast<float4*>(ring_smem + PE16_OFF + 16 * c) = e;
+constexpr int RING16_LDS_BYTES = RING_LDS_BYTES;
+// per-lane frequencies of the channel order above (pass-invariant; recomputed per pass, cheaper than keeping them)
+struct Pe16 {
+  float fa, fb, fc, phc;      // position: bands 2g, 2g+1, 8 + (g>>1); phase of the third (0 sin, 1/4 rev cos)
+  float fd;                   // direction: band g
+  int g;
+};
+__device__ __forceinline__ Pe16 pe16_setup(const PeFreq& fr, int g) {
+  Pe16 q;
+  q.fa = g == 0 ? fr.pos[0] : g == 1 ? fr.pos[2] : g == 2 ? fr.pos[4] : fr.pos[6];
+  q.fb = g == 0 ? fr.pos[1] : g == 1 ? fr.pos[3] : g == 2 ? fr.pos[5] : fr.pos[7];
+  q.fc = g < 2 ? fr.pos[8] : fr.pos[9];
+  q.phc = (g & 1) ? 0.25f : 0.0f;
+  q.fd = g == 0 ? fr.dir[0] : g == 1 ? fr.dir[1] : g == 2 ? fr.dir[2] : fr.dir[3];
+  q.g = g;
+  return q;
+}
+// sin(x f + phase [rev] 2 pi): x f is the reference's fp32 product; v_sin_f32 takes revolutions
+__device__ __forceinline__ float sin_rev(float x, float f, float ph) {
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf((x * f) * 0.15915494309189535f + ph));
+}
+__device__ __forceinline__ void pe16_pos(const Pe16& q, const float (&x)[3], bf16x8& k0, bf16x8& k1) {
+  float v[16];
+#pragma unroll
+  for (int sl = 0; sl < 12; ++sl) v[sl] = sin_rev(x[sl % 3], sl < 6 ? q.fa : q.fb, (sl % 6) >= 3 ? 0.25f : 0.0f);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) v[12 + d] = sin_rev(x[d], q.fc, q.phc);
+  v[15] = q.g == 0 ? x[0] : q.g == 1 ? x[1] : q.g == 2 ? x[2] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const bf16x2 a = pack2(v[j], v[j + 1]), b = pack2(v[8 + j], v[8 + j + 1]);
+    k0[j] = a[0]; k0[j + 1] = a[1]; k1[j] = b[0]; k1[j + 1] = b[1];
   }
 }
-__device__ __forceinline__ bf16x8 pe16_frag(const float (&x)[3], int c_base, int g, int table) {
-  bf16x8 v;
+__device__ __forceinline__ bf16x8 pe16_dir(const Pe16& q, const float (&x)[3]) {
+  float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = c_base + 16 * (j >> 2) + 4 * g + (j & 3);
-    const float4 e = *reinterpret_cast<const float4*>(ring_smem + PE16_OFF + 16 * (table + c));
-    const int dim = __float_as_int(e.z), kind = __float_as_int(e.w);
-    const float xv = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
-    const float t = __builtin_amdgcn_fractf((xv * e.x) * 0.15915494309189535f + e.y);
-    const float sv = __builtin_amdgcn_sinf(t);
-    v[j] = (__bf16)(kind == 0 ? xv : (kind == 3 ? 0.0f : sv));
-  }
-  return v;
+  for (int j = 0; j < 6; ++j) v[j] = sin_rev(x[j % 3], q.fd, j >= 3 ? 0.25f : 0.0f);
+  v[6] = q.g == 0 ? x[0] : q.g == 1 ? x[1] : q.g == 2 ? x[2] : 0.0f;
+  v[7] = 0.0f;
+  bf16x8 k;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) { const bf16x2 a = pack2(v[j], v[j + 1]); k[j] = a[0]; k[j + 1] = a[1]; }
+  return k;
 }
 
 // out[s][nt>>1] (elements 4 (nt&1) + i) = act( W[16-row tile nt] . in[s] + bias ), s = 0..NS-1 sample tiles of 16
@@ -875,6 +913,7 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wt
   const int c = lane & 15, g = lane >> 4;
   const int64_t wtile = wtile0 < nwtiles ? wtile0 : nwtiles - 1;
   bf16x8 pe[NS][2], dpe[NS][1];
+  const Pe16 pq = pe16_setup(a.fr, g);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     int64_t m = wtile * (16 * NS) + 16 * s + c; if (m >= a.M) m = a.M - 1;
@@ -889,8 +928,8 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wt
     for (int j = 0; j < 8; ++j) cst[j] = (__bf16)(p[0] + d[0]);
     pe[s][0] = cst; pe[s][1] = cst; dpe[s][0] = cst;
 #else
-    pe[s][0] = pe16_frag(p, 0, g, 0); pe[s][1] = pe16_frag(p, 32, g, 0);
-    dpe[s][0] = pe16_frag(d, 0, g, 64);
+    pe16_pos(pq, p, pe[s][0], pe[s][1]);
+    dpe[s][0] = pe16_dir(pq, d);
 #endif
   }
   bf16x8 ha[NS][8], hb[NS][8];
@@ -976,7 +1015,6 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
   ws.wv = wv;
   ws.start(lane);
   ring_load_bias(a.bias, L::BI_TOTAL);
-  pe16_build(a.fr);
   __syncthreads();
   NERF_STAMP_BEGIN();
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
@@ -1629,9 +1667,9 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   fill_freqs(a.fr, freq_mode);
   const int64_t ntiles = (M + 31) / 32;
   auto s = as_stream(stream);
-  // auto: fused query -> LDS ring on 32x32x16.  The 16x16x32 variants (4, 5) hold a higher clock and win back-to-back
-  // on random data (+3 %), but inside the train+render step of bench.py variant 3 is 4 % faster
-  const int variant = (g_mlp_variant == 0) ? (MODE == 1 ? 3 : 1) : g_mlp_variant;
+  // auto: fused query -> LDS ring; the render path (no activations kept) on the 16x16x32 shape, which holds a higher
+  // clock: +8 % back to back, +2.5 % inside bench.py's train+render step
+  const int variant = (g_mlp_variant == 0) ? (MODE == 1 ? (acts ? 3 : 4) : 1) : g_mlp_variant;
   if ((variant == 4 || variant == 5) && MODE == 1 && !acts) {
     const int64_t nsuper = (M + 255) / 256;
     const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs));
