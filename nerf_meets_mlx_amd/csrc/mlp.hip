@@ -1301,7 +1301,11 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
     __builtin_amdgcn_s_barrier();                       // tile landed for every wave; stage (tile-1)%4 is free
     if (tile + DW_STAGES - 1 < tile_hi) issue(tile + DW_STAGES - 1, (tile - tile_lo + DW_STAGES - 1) % DW_STAGES);
     const char* st = smem + ((tile - tile_lo) % DW_STAGES) * DW_STAGE_BYTES;
+#if NERF_ABLATE == 4          // timing-only: loads and synchronisation only
+    if (false) {
+#else
     if (active) {
+#endif
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         bf16x8 bfr[2];
@@ -1316,10 +1320,17 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
           const int nt = wr * 4 + i;
           const int f = (nt < n_tiles ? 2 * nt : 0) + fsel;
           const bf16x8 afr = tr_frag(st + f * DW_FRAG_STRIDE, u, hq, i16);
-          if (wc == 0) {
+#if NERF_ABLATE != 5          // timing-only build 5: no bias row sums
+          if (wc == 0) {                       // bias gradient = row sums of dZ: v_dot2c_f32_bf16 against (1, 1)
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bsum[i] += (float)afr[j];
+            for (int j = 0; j < 8; j += 2) {
+              const bf16x2_t pr = {afr[j], afr[j + 1]};
+              bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
+            }
           }
+#endif
 #pragma unroll
           for (int k = 0; k < 2; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[k], acc[i][k], 0, 0, 0);
         }
@@ -1327,6 +1338,9 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
     }
   }
   if (!active) return;
+#if NERF_ABLATE == 6          // timing-only build 6: no atomic epilogue
+  if (a.ntiles > 0) return;
+#endif
   const int rr = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -1567,6 +1581,8 @@ __global__ void __launch_bounds__(512, 2) mlp_img_bwd_ring_kernel(ImgArgs a) {
 }
 
 static int g_dw_wgs = 0;       // 0: automatic (see launch_dw)
+static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW only (on whatever dz holds)
+static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
 static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
 static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad16; }
@@ -1601,6 +1617,8 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 256; return NERF_OK; }
   if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 0; return NERF_OK; }
+  if (!strcmp(key, "bwd_stage")) { g_bwd_stage = value; return NERF_OK; }
+  if (!strcmp(key, "dw_job_mask")) { g_dw_job_mask = value; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -1838,8 +1856,9 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
     const int64_t nsuper = (ntiles + 7) / 8;
     static bool once = false;
     if (!once) { ensure_lds(mlp_bwd_ring_kernel, RING_LDS_BYTES); once = true; }
-    hipLaunchKernelGGL(mlp_bwd_ring_kernel, dim3((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), dim3(512),
-                       RING_LDS_BYTES, s, b);
+    if (g_bwd_stage != 2)
+      hipLaunchKernelGGL(mlp_bwd_ring_kernel, dim3((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), dim3(512),
+                         RING_LDS_BYTES, s, b);
   } else {
     const int st = variant == 2 ? 2 : 1;
     const int64_t blocks = (ntiles + 4 * st - 1) / (4 * st);
@@ -1848,10 +1867,12 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   }
   int rc = check_launch("mlp backward chain");
   if (rc) return rc;
+  if (g_bwd_stage == 1) return NERF_OK;
   // ---- 2. dW / db
   DwArgs d;
-  int nj = 0;
+  int nj = 0, jseq = 0;
   auto job = [&](int dz_slot, int nf, int act_slot, int kf, int w_off, int ldw, int col0, int nv, int kv, int b_off) {
+    if (g_dw_job_mask && !((g_dw_job_mask >> jseq++) & 1)) return;
     d.jobs[nj++] = DwJob{dz_slot, nf, act_slot, kf, w_off, ldw, col0, nv, kv, b_off};
   };
   job(L::Z_L0, 16, L::A_PE, 4, L::P_W0, 63, 0, 256, 63, L::P_B0);                                  // pos0

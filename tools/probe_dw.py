@@ -1,5 +1,5 @@
-"""Probe: dW workgroup count sweep + kernel-level timings of one training step (B=4096, n=192)."""
-import sys, torch
+"""Probe: the weight-gradient kernel alone (bwd_stage 2), whole job list and per job, B=4096 x n=192 samples."""
+import os, sys, torch
 sys.path.insert(0, ".")
 from nerf_meets_mlx_amd import _native
 from nerf_meets_mlx_amd.models.NeRF import NeRF
@@ -16,12 +16,24 @@ def timeit(fn, it=8):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
+tag = os.path.basename(os.environ.get("NERF_HIP_LIB", "default"))
+opt = lambda k, v: _native.check(_native.lib().nerf_set_option(k, v))
 m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0)
-for B, n in ((4096, 64), (4096, 192)):
-    r = rays(B); z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
-    g = torch.randn(B, n, 4, device=dev)
-    m.query(r, z, train=True)
-    for wgs in (512, 768, 1024, 1536, 2048, 3072):
-        _native.check(_native.lib().nerf_set_option(b"dw_workgroups", wgs))
-        ms = timeit(lambda: m.backward(g))
-        print(f"B={B} n={n} dw_workgroups={wgs}: bwd chain + dW {ms:.3f} ms", flush=True)
+B, n = 4096, 192
+r = rays(B); z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
+g = torch.randn(B, n, 4, device=dev)
+m.query(r, z, train=True)
+m.backward(g)
+names = ["pos0", "pos1", "pos2", "pos3", "pos4", "pos5|H4", "pos5|PE", "pos6", "pos7", "feature", "alpha", "dir0|feat", "dir0|dPE", "rgb"]
+frags = [20, 32, 32, 32, 32, 32, 20, 32, 32, 32, 17, 24, 10, 9]
+opt(b"bwd_stage", 1); t_chain = timeit(lambda: m.backward(g))
+opt(b"bwd_stage", 2); t_dw = timeit(lambda: m.backward(g))
+tot = sum(frags) * 1024 * (B * n / 32)
+print(f"[{tag}] chain {t_chain:.3f} ms | dW all jobs {t_dw:.3f} ms = {tot/t_dw/1e9:.2f} TB/s", flush=True)
+if "--jobs" in sys.argv:
+    for j, (nm, fr) in enumerate(zip(names, frags)):
+        opt(b"dw_job_mask", 1 << j)
+        t = timeit(lambda: m.backward(g))
+        print(f"[{tag}]   job {nm:10s} {fr:2d} frags/tile: {t:.3f} ms = {fr*1024*(B*n/32)/t/1e9:.2f} TB/s", flush=True)
+    opt(b"dw_job_mask", 0)
+opt(b"bwd_stage", 0)
