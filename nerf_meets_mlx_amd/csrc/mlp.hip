@@ -399,6 +399,53 @@ __device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws
 // ------------------------------------------------------------------------------------------
 // one linear layer on register-resident activations
 // ------------------------------------------------------------------------------------------
+// fragment block address: tile T, slot s, lane (r,h) at byte 32 r + 16 h.  Written as (uniform 64-bit tile base) +
+// (constant slot offset) + (32-bit lane offset) so that hipcc keeps the base in SGPRs.
+__device__ __forceinline__ bf16x8* frag_ptr(void* base, int64_t tile, int64_t stride16, int slot, int r, int h) {
+  char* tb = reinterpret_cast<char*>(base) + tile * stride16 * 16;
+  return reinterpret_cast<bf16x8*>(tb + slot * 1024 + (unsigned)(32 * r + 16 * h));
+}
+
+#ifndef NERF_NT_STORES
+#define NERF_NT_STORES 1
+#endif
+constexpr bool g_nt_stores = NERF_NT_STORES != 0;
+
+// one fragment of a fragment block.  Written once, read once by a later kernel: non-temporal, so that the 5 KB/sample
+// store stream does not push the 2.4 MB weight stream (which every workgroup re-reads through the ring) out of L2
+__device__ __forceinline__ void store_frag(void* base, int64_t tile, int64_t stride16, int slot, const bf16x8& v,
+                                           int r, int h) {
+#if NERF_ABLATE == 7          // timing-only build 7: no fragment stores at all (values kept alive)
+  asm volatile("" :: "v"(v));
+  return;
+#endif
+#if NERF_ABLATE == 8          // timing-only build 8: every tile stored over tiles 0-7 (L2-resident: issue cost without HBM)
+  tile = tile & 7;
+#endif
+  if (g_nt_stores) __builtin_nontemporal_store(v, frag_ptr(base, tile, stride16, slot, r, h));
+  else *frag_ptr(base, tile, stride16, slot, r, h) = v;
+}
+template <int COUNT>
+__device__ __forceinline__ void store_frags(void* base, int64_t tile, int64_t stride16, int slot0,
+                                            const bf16x8 (&frags)[COUNT], int r, int h) {
+#pragma unroll
+  for (int k = 0; k < COUNT; ++k) store_frag(base, tile, stride16, slot0 + k, frags[k], r, h);
+}
+// Where a layer's output fragments go besides the next layer: nowhere (inference), or into the fragment block of the
+// sample tile as soon as each pair of fragments is final.  A burst of 16 stores per wave behind the layer (128 KiB per
+// workgroup, all 8 waves at once) backs up the CU's store path and stalls the waves at issue: measured 0.21 ms of a
+// 0.94 ms chain even with the bytes staying in L2 (NERF_ABLATE 8); two stores per n-tile keep the path draining.
+struct NoSink {
+  __device__ __forceinline__ void put(int, int, const bf16x8&) const {}
+};
+template <bool ON>
+struct FragSink {
+  void* base; int64_t tile0, stride16; int slot0, r, h;
+  __device__ __forceinline__ void put(int t, int idx, const bf16x8& v) const {
+    if (ON) store_frag(base, tile0 + t, stride16, slot0 + idx, v, r, h);
+  }
+};
+
 template <class WS>
 __device__ __forceinline__ void acc_init_bias(f32x16& acc, WS& ws, int slot_tile, int h) {
   // register i <-> row (i&3) + 8 (i>>2) + 4 h : four float4 at rows 8g + 4h
@@ -434,9 +481,10 @@ __host__ __device__ constexpr int quarter_pos(int ks_count, int q) {   // k-step
 }
 
 // out[t][2 nt + s] = act( W[nt-tile] . in[t] + bias );  fragments fbase + nt*KS + ks of the stream
-template <int ST, int KS, int NT, bool RELU, bool MASKOUT, class WS>
+template <int ST, int KS, int NT, bool RELU, bool MASKOUT, class WS, class SINK = NoSink>
 __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, const bf16x8 (&in)[ST][KS],
-                                          bf16x8 (&out)[ST][2 * NT], u32x4 (&mask)[ST], int lane) {
+                                          bf16x8 (&out)[ST][2 * NT], u32x4 (&mask)[ST], int lane,
+                                          const SINK& sink = SINK()) {
   const int h = lane >> 5;
   f32x16 prev[ST];
 #pragma unroll
@@ -455,8 +503,10 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
         for (int q = 0; q < 4; ++q)
           if (quarter_pos(KS, q) == ks) {
 #pragma unroll
-            for (int t = 0; t < ST; ++t)
+            for (int t = 0; t < ST; ++t) {
               finish_quarter<RELU, MASKOUT>(prev[t], q, nt - 1, out[t][2 * nt - 2], out[t][2 * nt - 1], mask[t]);
+              if (q == 3) { sink.put(t, 2 * nt - 2, out[t][2 * nt - 2]); sink.put(t, 2 * nt - 1, out[t][2 * nt - 1]); }
+            }
           }
       }
     }
@@ -468,30 +518,8 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
 #pragma unroll
     for (int t = 0; t < ST; ++t)
       finish_quarter<RELU, MASKOUT>(prev[t], q, NT - 1, out[t][2 * NT - 2], out[t][2 * NT - 1], mask[t]);
-}
-
-// fragment block address: tile T, slot s, lane (r,h) at byte 32 r + 16 h.  Written as (uniform 64-bit tile base) +
-// (constant slot offset) + (32-bit lane offset) so that hipcc keeps the base in SGPRs.
-__device__ __forceinline__ bf16x8* frag_ptr(void* base, int64_t tile, int64_t stride16, int slot, int r, int h) {
-  char* tb = reinterpret_cast<char*>(base) + tile * stride16 * 16;
-  return reinterpret_cast<bf16x8*>(tb + slot * 1024 + (unsigned)(32 * r + 16 * h));
-}
-
-#ifndef NERF_NT_STORES
-#define NERF_NT_STORES 1
-#endif
-constexpr bool g_nt_stores = NERF_NT_STORES != 0;
-
-template <int COUNT>
-__device__ __forceinline__ void store_frags(void* base, int64_t tile, int64_t stride16, int slot0,
-                                            const bf16x8 (&frags)[COUNT], int r, int h) {
-  // written once, read once by a later kernel: non-temporal, so that the 5 KB/sample store stream does not push the
-  // 2.4 MB weight stream (which every workgroup re-reads through the ring) out of L2
 #pragma unroll
-  for (int k = 0; k < COUNT; ++k) {
-    if (g_nt_stores) __builtin_nontemporal_store(frags[k], frag_ptr(base, tile, stride16, slot0 + k, r, h));
-    else *frag_ptr(base, tile, stride16, slot0 + k, r, h) = frags[k];
-  }
+  for (int t = 0; t < ST; ++t) { sink.put(t, 2 * NT - 2, out[t][2 * NT - 2]); sink.put(t, 2 * NT - 1, out[t][2 * NT - 1]); }
 }
 
 struct FwdArgs {
@@ -551,35 +579,26 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
 
   bf16x8 ha[ST][16], hb[ST][16];
   u32x4 mk[ST];
+#define SINK(slot0) FragSink<STORE>{a.acts, tile0, a.astride, slot0, r, h}
 #define MASK_BEGIN() do { _Pragma("unroll") for (int t = 0; t < ST; ++t) mk[t] = u32x4{0u, 0u, 0u, 0u}; } while (0)
 #define MASK_STORE(layer) do { if (STORE) { _Pragma("unroll") for (int t = 0; t < ST; ++t) \
     *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0 + t, a.astride, L::A_MASK + (layer), r, h)) = mk[t]; ws.note_stores(ST); } } while (0)
   MASK_BEGIN();
-  layer_fwd<ST, 4, 8, true, STORE>(ws, L::F_L0, 0, pe, ha, mk, lane);
+  layer_fwd<ST, 4, 8, true, STORE>(ws, L::F_L0, 0, pe, ha, mk, lane, SINK(L::A_H0));
   MASK_STORE(0);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0, t, ha[t], 16);
   // pos1..pos4 (ping-pong)
   MASK_BEGIN();
-  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 0 * 128, 256, ha, hb, mk, lane);
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 0 * 128, 256, ha, hb, mk, lane, SINK(L::A_H0 + 16));
   MASK_STORE(1);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0 + 16, t, hb[t], 16);
   MASK_BEGIN();
-  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 1 * 128, 512, hb, ha, mk, lane);
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 1 * 128, 512, hb, ha, mk, lane, SINK(L::A_H0 + 32));
   MASK_STORE(2);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0 + 32, t, ha[t], 16);
   MASK_BEGIN();
-  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 2 * 128, 768, ha, hb, mk, lane);
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 2 * 128, 768, ha, hb, mk, lane, SINK(L::A_H0 + 48));
   MASK_STORE(3);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0 + 48, t, hb[t], 16);
   MASK_BEGIN();
-  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 3 * 128, 1024, hb, ha, mk, lane);
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L1 + 3 * 128, 1024, hb, ha, mk, lane, SINK(L::A_H0 + 64));
   MASK_STORE(4);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0 + 64, t, ha[t], 16);
   // pos5 on concat[input_pos, h]  (models/NeRF.py:224-225)
   {
     bf16x8 cat[ST][20];
@@ -595,25 +614,17 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
       for (int k = 0; k < 16; ++k) cat[t][4 + k] = ha[t][k];
     }
     MASK_BEGIN();
-    layer_fwd<ST, 20, 8, true, STORE>(ws, L::F_L5, 1280, cat, hb, mk, lane);
+    layer_fwd<ST, 20, 8, true, STORE>(ws, L::F_L5, 1280, cat, hb, mk, lane, SINK(L::A_H0 + 80));
     MASK_STORE(5);
   }
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0 + 80, t, hb[t], 16);
   MASK_BEGIN();
-  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L6, 1536, hb, ha, mk, lane);
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L6, 1536, hb, ha, mk, lane, SINK(L::A_H0 + 96));
   MASK_STORE(6);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0 + 96, t, ha[t], 16);
   MASK_BEGIN();
-  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L7, 1792, ha, hb, mk, lane);
+  layer_fwd<ST, 16, 8, true, STORE>(ws, L::F_L7, 1792, ha, hb, mk, lane, SINK(L::A_H0 + 112));
   MASK_STORE(7);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_H0 + 112, t, hb[t], 16);
   // feature (no activation) and alpha (row 0 of a ninth tile)   models/NeRF.py:229-231
-  layer_fwd<ST, 16, 8, false, false>(ws, L::F_FA, L::BI_FEAT, hb, ha, mk, lane);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_FEAT, t, ha[t], 16);
+  layer_fwd<ST, 16, 8, false, false>(ws, L::F_FA, L::BI_FEAT, hb, ha, mk, lane, SINK(L::A_FEAT));
   float alpha[ST];
   {
     f32x16 acc[ST];
@@ -644,11 +655,9 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
       cat[t][16] = dpe[t][0]; cat[t][17] = dpe[t][1];
     }
     MASK_BEGIN();
-    layer_fwd<ST, 18, 4, true, STORE>(ws, L::F_DIR, L::BI_DIR, cat, hd, mk, lane);
+    layer_fwd<ST, 18, 4, true, STORE>(ws, L::F_DIR, L::BI_DIR, cat, hd, mk, lane, SINK(L::A_HD));
     MASK_STORE(8);
   }
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::A_HD, t, hd[t], 8);
   {
     f32x16 acc[ST];
     acc_init_bias(acc[0], ws, L::BI_RGB, h);
@@ -670,6 +679,7 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
     }
   }
 #undef store
+#undef SINK
 #undef MASK_BEGIN
 #undef MASK_STORE
 }
@@ -1045,9 +1055,9 @@ __device__ __forceinline__ void finish_quarter_bwd(const f32x16& acc, int q, int
 }
 
 // out[t][2 kt + s] = mask( W^T[kt-tile] . in[t] );  mask = ReLU sign bits written by the forward kernel
-template <int ST, int NS, int KT, bool MASK, class WS>
+template <int ST, int NS, int KT, bool MASK, class WS, class SINK = NoSink>
 __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&in)[ST][NS], bf16x8 (&out)[ST][2 * KT],
-                                          const u32x4 (&mask)[ST], int lane) {
+                                          const u32x4 (&mask)[ST], int lane, const SINK& sink = SINK()) {
   f32x16 prev[ST];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -1066,8 +1076,10 @@ __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&in)[
         for (int q = 0; q < 4; ++q)
           if (quarter_pos(NS, q) == ns) {
 #pragma unroll
-            for (int t = 0; t < ST; ++t)
+            for (int t = 0; t < ST; ++t) {
               finish_quarter_bwd<MASK>(prev[t], q, kt - 1, out[t][2 * kt - 2], out[t][2 * kt - 1], mask[t]);
+              if (q == 3) { sink.put(t, 2 * kt - 2, out[t][2 * kt - 2]); sink.put(t, 2 * kt - 1, out[t][2 * kt - 1]); }
+            }
           }
       }
     }
@@ -1079,6 +1091,8 @@ __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&in)[
 #pragma unroll
     for (int t = 0; t < ST; ++t)
       finish_quarter_bwd<MASK>(prev[t], q, KT - 1, out[t][2 * KT - 2], out[t][2 * KT - 1], mask[t]);
+#pragma unroll
+  for (int t = 0; t < ST; ++t) { sink.put(t, 2 * KT - 2, out[t][2 * KT - 2]); sink.put(t, 2 * KT - 1, out[t][2 * KT - 1]); }
 }
 
 struct BwdArgs {
@@ -1120,14 +1134,11 @@ __device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile
 #pragma unroll
   for (int t = 0; t < ST; ++t) { store(L::Z_RGB, t, zrgb[t], 1); store(L::Z_A, t, zal[t], 1); }
 
+#define ZSINK(slot0) FragSink<true>{a.dz, tile0, a.zstride, slot0, r, h}
   bf16x8 zd[ST][8];
-  layer_bwd<ST, 1, 4, true>(ws, L::B_RGB, zrgb, zd, mk[8], lane);
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_D, t, zd[t], 8);
+  layer_bwd<ST, 1, 4, true>(ws, L::B_RGB, zrgb, zd, mk[8], lane, ZSINK(L::Z_D));
   bf16x8 za[ST][16], zb[ST][16];
-  layer_bwd<ST, 8, 8, false>(ws, L::B_DIR, zd, za, mk[8], lane);            // d feature
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_F, t, za[t], 16);
+  layer_bwd<ST, 8, 8, false>(ws, L::B_DIR, zd, za, mk[8], lane, ZSINK(L::Z_F));            // d feature
   {
     bf16x8 cat[ST][17];
 #pragma unroll
@@ -1136,32 +1147,17 @@ __device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile
       for (int k = 0; k < 16; ++k) cat[t][k] = za[t][k];
       cat[t][16] = zal[t][0];
     }
-    layer_bwd<ST, 17, 8, true>(ws, L::B_FA, cat, zb, mk[7], lane);   // dZ7
+    layer_bwd<ST, 17, 8, true>(ws, L::B_FA, cat, zb, mk[7], lane, ZSINK(L::Z_L0 + 112));   // dZ7
   }
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 112, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(ws, L::B_L7, zb, za, mk[6], lane);       // dZ6
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 96, t, za[t], 16);
-  layer_bwd<ST, 16, 8, true>(ws, L::B_L6, za, zb, mk[5], lane);       // dZ5
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 80, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(ws, L::B_L5, zb, za, mk[4], lane);       // dZ4
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 64, t, za[t], 16);
-  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 0 * 128, za, zb, mk[3], lane);   // dZ3
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 48, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 1 * 128, zb, za, mk[2], lane);   // dZ2
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 32, t, za[t], 16);
-  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 2 * 128, za, zb, mk[1], lane);   // dZ1
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 16, t, zb[t], 16);
-  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 3 * 128, zb, za, mk[0], lane);    // dZ0
-#pragma unroll
-  for (int t = 0; t < ST; ++t) store(L::Z_L0 + 0, t, za[t], 16);
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L7, zb, za, mk[6], lane, ZSINK(L::Z_L0 + 96));       // dZ6
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L6, za, zb, mk[5], lane, ZSINK(L::Z_L0 + 80));       // dZ5
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L5, zb, za, mk[4], lane, ZSINK(L::Z_L0 + 64));       // dZ4
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 0 * 128, za, zb, mk[3], lane, ZSINK(L::Z_L0 + 48));   // dZ3
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 1 * 128, zb, za, mk[2], lane, ZSINK(L::Z_L0 + 32));   // dZ2
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 2 * 128, za, zb, mk[1], lane, ZSINK(L::Z_L0 + 16));   // dZ1
+  layer_bwd<ST, 16, 8, true>(ws, L::B_L4 + 3 * 128, zb, za, mk[0], lane, ZSINK(L::Z_L0 + 0));    // dZ0
 #undef store
+#undef ZSINK
 }
 
 template <int ST>

@@ -25,5 +25,10 @@ for rep in range(2):
         f = timeit(lambda: m.query(r, z, train=True))
         m.query(r, z, train=True)
         b = timeit(lambda: m.backward(g))
+        _native.check(_native.lib().nerf_set_option(b"bwd_stage", 1))
+        c = timeit(lambda: m.backward(g))
+        _native.check(_native.lib().nerf_set_option(b"bwd_stage", 0))
+        _native.check(_native.lib().nerf_set_option(b"mlp_variant", 3))
         i = timeit(lambda: m.query(r, z))
-        print(f"[{tag}] B={B} n={n}: fwd-train {f:.3f} ms  bwd+dW {b:.3f} ms  fwd-infer {i:.3f} ms", flush=True)
+        _native.check(_native.lib().nerf_set_option(b"mlp_variant", 0))
+        print(f"[{tag}] B={B} n={n}: fwd-train {f:.3f} ms  bwd+dW {b:.3f} ms (chain {c:.3f})  fwd-infer(v3) {i:.3f} ms", flush=True)
