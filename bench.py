@@ -163,7 +163,7 @@ def main():
         "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
         "train_mfma_frac": train_tf / BF16_MFMA_PEAK_TFLOPS, "render_mfma_frac": render_tf / BF16_MFMA_PEAK_TFLOPS,
         "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
-        "roofline": {"bound": "mfma", "kernel": "mlp_fwd_ring_kernel (render fine pass)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": ("mlp_fwd_ring16_kernel<8,2>" if args.mlp_variant in (0, 4) else f"fused MLP forward, mlp_variant {args.mlp_variant}") + " (render fine pass)", "achieved": achieved,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
                      "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * n_fine},
@@ -203,8 +203,11 @@ def cpu_baseline(args):
             O.render_rays_eval(arch, pc, pf, O.pack_rays(o, d, 2.0, 6.0), 64, 128, torch.rand(b_render, 128, generator=g), True)
     one()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    done = 0
+    while done < steps or (time.perf_counter() - t0 < 10.0 and done < 4 * steps):     # 10-30 s of CPU work
         one()
+        done += 1
+    steps = done
     dt = time.perf_counter() - t0
     return {"value": (b_train + b_render) * steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps of (train {b_train} rays + render {b_render} rays), coarse+fine 64+128, torch-CPU fp32 oracle",

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Turn raw rocprofv3 output (gpurun_out/...) into the small summaries committed under profiles/.
+
+    python tools/summarize_rocprof.py --round r01 --stats gpurun_out/prof_bench --fetch gpurun_out/pmc_fetch \
+        --write gpurun_out/pmc_write [--render-samples 6291456]
+
+--stats : directory of `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline`
+--fetch / --write : directories of the two separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of
+                    `python bench.py --steps 4 --warmup 2 --no-cpu-baseline`
+Only kernels of this library (namespace nerf::) are kept."""
+import argparse, csv, glob, json, os, re, statistics
+from collections import defaultdict
+
+FLOP_PER_SAMPLE = 2 * 593408
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits[-1]
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(nerf::\w+\)$|\(.*\)$", "", name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", default="r01")
+    ap.add_argument("--stats")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--render-samples", type=int, default=32768 * 192)
+    ap.add_argument("--out", default="profiles")
+    a = ap.parse_args()
+    R = a.round
+    if a.stats:
+        rows = [r for r in csv.DictReader(open(find(a.stats, "_kernel_stats.csv"))) if "nerf::" in r["Name"]]
+        with open(os.path.join(a.out, f"{R}_bench_kernel_stats.csv"), "w", newline="") as fp:
+            w = csv.writer(fp)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+        groups = defaultdict(list)
+        for r in csv.DictReader(open(find(a.stats, "_kernel_trace.csv"))):
+            if "nerf::" not in r["Kernel_Name"]:
+                continue
+            key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]), r["VGPR_Count"],
+                   r["Accum_VGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
+            groups[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        with open(os.path.join(a.out, f"{R}_bench_kernel_trace_summary.csv"), "w", newline="") as fp:
+            w = csv.writer(fp)
+            w.writerow(["kernel", "grid_x", "wg_x", "vgpr", "agpr", "lds", "scratch", "launches", "avg_us", "min_us", "max_us"])
+            for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow(list(k) + [len(v), f"{statistics.mean(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}"])
+        # the render-path forward kernel, split by launch duration class (coarse 64 / fine 192 samples per ray)
+        fwd = [(k, v) for k, v in groups.items() if "mlp_fwd_ring16_kernel" in k[0] or k[0].startswith("nerf::mlp_fwd_ring_kernel<1, false>")]
+        with open(os.path.join(a.out, f"{R}_dominant_kernel_launches.csv"), "w", newline="") as fp:
+            w = csv.writer(fp)
+            w.writerow(["kernel", "class", "samples_per_launch", "launches", "avg_us", "min_us", "max_us", "algorithmic_TFLOPs"])
+            for k, v in fwd:
+                big = [x for x in v if x > 0.6 * max(v)]
+                mid = [x for x in v if 0.2 * max(v) < x <= 0.6 * max(v)]
+                for label, xs, samples in (("render fine pass", big, a.render_samples), ("render coarse pass", mid, a.render_samples // 3)):
+                    if xs:
+                        avg = statistics.mean(xs)
+                        w.writerow([k[0], label, samples, len(xs), f"{avg:.1f}", f"{min(xs):.1f}", f"{max(xs):.1f}",
+                                    f"{FLOP_PER_SAMPLE * samples / (avg * 1e-6) / 1e12:.1f}"])
+    if a.fetch and a.write:
+        per = defaultdict(lambda: defaultdict(list))
+        for ctr, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+            for r in csv.DictReader(open(find(d, "_counter_collection.csv"))):
+                if "nerf::mlp" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                    per[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][ctr].append(
+                        (float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        with open(os.path.join(a.out, f"{R}_pmc_mlp_kernels.csv"), "w", newline="") as fp:
+            w = csv.writer(fp)
+            w.writerow(["kernel", "grid", "launches", "FETCH_SIZE_KB_max", "WRITE_SIZE_KB_max", "avg_us"])
+            best = None
+            for (k, g), c in sorted(per.items()):
+                f = max((x[0] for x in c["FETCH_SIZE"]), default=0.0)
+                wr = max((x[0] for x in c["WRITE_SIZE"]), default=0.0)
+                us = statistics.mean([x[1] for x in c["FETCH_SIZE"] + c["WRITE_SIZE"]])
+                w.writerow([k, g, len(c["FETCH_SIZE"]), f"{f:.0f}", f"{wr:.0f}", f"{us:.1f}"])
+                if ("mlp_fwd_ring16_kernel" in k or k.startswith("nerf::mlp_fwd_ring_kernel<1, false>")) and (best is None or wr > best[2]):
+                    best = (k, f, wr)
+        if best:
+            with open(os.path.join(a.out, f"{R}_pmc_traffic.json"), "w") as fp:
+                json.dump({"kernel": best[0], "samples_per_launch": a.render_samples, "FETCH_SIZE_KB": round(best[1]),
+                           "WRITE_SIZE_KB": round(best[2]),
+                           "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --steps 4 --warmup 2`; "
+                                   "largest launch of the render forward = the fine pass; FETCH_SIZE left uncorrected (4-byte-per-lane z loads "
+                                   "and L2-missing weight refills, not the 16-B streaming pattern the guide's x2 applies to)",
+                           "hbm_bytes_per_launch": int((best[1] + best[2]) * 1024)}, fp, indent=1)
+
+
+if __name__ == "__main__":
+    main()
