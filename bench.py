@@ -151,6 +151,16 @@ def main():
             traffic = pm["hbm_bytes_per_launch"]
     except OSError:
         pass
+    # matrix-pipe busy cycles / all SIMD cycles of that kernel (PMC passes committed under profiles/), null if absent
+    busy = None
+    try:
+        import csv
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_lds.csv")) as fp:
+            for r in csv.DictReader(fp):
+                if "mlp_fwd_ring16_kernel<8, 2>" in r["kernel"] and args.mlp_variant in (0, 4) and traffic is not None:
+                    busy = float(r["mfma_busy_frac_of_cycles"])
+    except OSError:
+        pass
     line = {
         "metric": f"train+render rays/sec on Lego {H}x{W} (synthetic), " + (f"coarse+fine 64+{NI}" if NI > 0 else "coarse-only 64"),
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +175,7 @@ def main():
         "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
         "roofline": {"bound": "mfma", "kernel": ("mlp_fwd_ring16_kernel<8,2>" if args.mlp_variant in (0, 4) else f"fused MLP forward, mlp_variant {args.mlp_variant}") + " (render fine pass)", "achieved": achieved,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "mfma_busy_cycles_frac": busy, "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
                      "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * n_fine},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -43,7 +43,7 @@ def test_host_argument_validation_without_gpu():
                                       None, None) == -2                      # NERF_E_SHAPE
     arch = _native.MlpArch(8, 256, 63, 27, 4, 1, 4)
     assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844
-    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == (1184 + 1120) * 1024 + 2496 * 4
+    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == (1184 + 1120) * 1024 + 2496 * 4 + 1184 * 1024   # + 16x16x32 stream
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
     img = _native.MlpArch(8, 256, 40, 0, 4, 0, 3)
     assert lib.nerf_mlp_param_count(C.byref(img)) == 482051
