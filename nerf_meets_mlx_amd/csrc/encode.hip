@@ -88,58 +88,78 @@ __device__ __forceinline__ uint32_t hash3(uint32_t cx, uint32_t cy, uint32_t cz,
   return ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) & mask;     // uint32 wrap-around, mod T = & (T-1)
 }
 
-// one thread per (sample, level): 8 gathers of F floats from an L2/Infinity-Cache resident table
-template <int F, bool BWD>
-__global__ void hashgrid_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ tables,
-                                float* __restrict__ d_tables, const float* __restrict__ d_out, int L, uint32_t T,
-                                ResTab rt, float* __restrict__ out) {
-  const int64_t total = M * L;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = t / L; const int l = (int)(t - m * L);
-    const float r = rt.res[l];
-    float off[3]; uint32_t cf[3], cc[3];
+// One thread per sample, blockIdx.y = a group of LG consecutive levels: at any time a workgroup's 256 neighbouring
+// samples gather from ONE level table (the coarse ones are a few KiB and stay in L1/L2; with one thread per
+// (sample, level) every lane of a wave hit a different 4 MiB table), and a thread's LG x F outputs / incoming gradients
+// are contiguous in the row (32 B for LG = 4, F = 2) instead of 8-byte pieces at a 128-byte stride.
+template <int F, bool BWD, int LG>
+__global__ void __launch_bounds__(256) hashgrid_kernel(const float* __restrict__ x, int64_t M,
+                                                       const float* __restrict__ tables, float* __restrict__ d_tables,
+                                                       const float* __restrict__ d_out, int L, uint32_t T, ResTab rt,
+                                                       float* __restrict__ out) {
+  const int l0 = blockIdx.y * LG;
+  const uint32_t mask = T - 1;
+  for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    const float px = x[3 * m], py = x[3 * m + 1], pz = x[3 * m + 2];
+    float vals[LG * F];
+    if (BWD) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float xs = x[3 * m + a] * r;
-      const float fl = floorf(xs);
-      off[a] = xs - fl;
-      cf[a] = (uint32_t)(int32_t)fl; cc[a] = (uint32_t)(int32_t)ceilf(xs);
+      for (int i = 0; i < LG * F; ++i) vals[i] = (l0 + i / F < L) ? d_out[(m * L + l0) * F + i] : 0.0f;
     }
-    const uint32_t mask = T - 1;
-    // reference corner numbering: 0=(c,c,c) 1=(c,f,c) 2=(f,f,c) 3=(f,c,c) 4=(c,c,f) 5=(c,f,f) 6=(f,f,f) 7=(f,c,f)
-    const uint32_t i0 = hash3(cc[0], cc[1], cc[2], mask), i1 = hash3(cc[0], cf[1], cc[2], mask);
-    const uint32_t i2 = hash3(cf[0], cf[1], cc[2], mask), i3 = hash3(cf[0], cc[1], cc[2], mask);
-    const uint32_t i4 = hash3(cc[0], cc[1], cf[2], mask), i5 = hash3(cc[0], cf[1], cf[2], mask);
-    const uint32_t i6 = hash3(cf[0], cf[1], cf[2], mask), i7 = hash3(cf[0], cc[1], cf[2], mask);
-    const float ox = off[0], oy = off[1], oz = off[2];
-    const size_t base = (size_t)l * T * F;
+#pragma unroll
+    for (int li = 0; li < LG; ++li) {
+      const int l = l0 + li;
+      if (l >= L) break;
+      const float r = rt.res[l];
+      const float p[3] = {px, py, pz};
+      float off[3]; uint32_t cf[3], cc[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float xs = p[a] * r;
+        const float fl = floorf(xs);
+        off[a] = xs - fl;
+        cf[a] = (uint32_t)(int32_t)fl; cc[a] = (uint32_t)(int32_t)ceilf(xs);
+      }
+      // reference corner numbering: 0=(c,c,c) 1=(c,f,c) 2=(f,f,c) 3=(f,c,c) 4=(c,c,f) 5=(c,f,f) 6=(f,f,f) 7=(f,c,f)
+      const uint32_t i0 = hash3(cc[0], cc[1], cc[2], mask), i1 = hash3(cc[0], cf[1], cc[2], mask);
+      const uint32_t i2 = hash3(cf[0], cf[1], cc[2], mask), i3 = hash3(cf[0], cc[1], cc[2], mask);
+      const uint32_t i4 = hash3(cc[0], cc[1], cf[2], mask), i5 = hash3(cc[0], cf[1], cf[2], mask);
+      const uint32_t i6 = hash3(cf[0], cf[1], cf[2], mask), i7 = hash3(cf[0], cc[1], cf[2], mask);
+      const float ox = off[0], oy = off[1], oz = off[2];
+      const size_t base = (size_t)l * T * F;
+      if (!BWD) {
+        const float* tb = tables + base;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const float h03 = tb[(size_t)i0 * F + f] * ox + tb[(size_t)i3 * F + f] * (1 - ox);
+          const float h12 = tb[(size_t)i1 * F + f] * ox + tb[(size_t)i2 * F + f] * (1 - ox);
+          const float h56 = tb[(size_t)i5 * F + f] * ox + tb[(size_t)i6 * F + f] * (1 - ox);
+          const float h47 = tb[(size_t)i4 * F + f] * ox + tb[(size_t)i7 * F + f] * (1 - ox);
+          const float h0312 = h03 * oy + h12 * (1 - oy);
+          const float h4756 = h47 * oy + h56 * (1 - oy);
+          vals[li * F + f] = h0312 * oz + h4756 * (1 - oz);
+        }
+      } else {
+        float* tb = d_tables + base;
+        const float wx1 = ox, wx0 = 1 - ox, wy1 = oy, wy0 = 1 - oy, wz1 = oz, wz0 = 1 - oz;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const float g = vals[li * F + f];
+          atomicAdd(tb + (size_t)i0 * F + f, g * wz1 * wy1 * wx1);
+          atomicAdd(tb + (size_t)i3 * F + f, g * wz1 * wy1 * wx0);
+          atomicAdd(tb + (size_t)i1 * F + f, g * wz1 * wy0 * wx1);
+          atomicAdd(tb + (size_t)i2 * F + f, g * wz1 * wy0 * wx0);
+          atomicAdd(tb + (size_t)i4 * F + f, g * wz0 * wy1 * wx1);
+          atomicAdd(tb + (size_t)i7 * F + f, g * wz0 * wy1 * wx0);
+          atomicAdd(tb + (size_t)i5 * F + f, g * wz0 * wy0 * wx1);
+          atomicAdd(tb + (size_t)i6 * F + f, g * wz0 * wy0 * wx0);
+        }
+      }
+    }
     if (!BWD) {
-      const float* tb = tables + base;
 #pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const float h03 = tb[(size_t)i0 * F + f] * ox + tb[(size_t)i3 * F + f] * (1 - ox);
-        const float h12 = tb[(size_t)i1 * F + f] * ox + tb[(size_t)i2 * F + f] * (1 - ox);
-        const float h56 = tb[(size_t)i5 * F + f] * ox + tb[(size_t)i6 * F + f] * (1 - ox);
-        const float h47 = tb[(size_t)i4 * F + f] * ox + tb[(size_t)i7 * F + f] * (1 - ox);
-        const float h0312 = h03 * oy + h12 * (1 - oy);
-        const float h4756 = h47 * oy + h56 * (1 - oy);
-        out[(m * L + l) * F + f] = h0312 * oz + h4756 * (1 - oz);
-      }
-    } else {
-      float* tb = d_tables + base;
-      const float wx1 = ox, wx0 = 1 - ox, wy1 = oy, wy0 = 1 - oy, wz1 = oz, wz0 = 1 - oz;
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const float g = d_out[(m * L + l) * F + f];
-        atomicAdd(tb + (size_t)i0 * F + f, g * wz1 * wy1 * wx1);
-        atomicAdd(tb + (size_t)i3 * F + f, g * wz1 * wy1 * wx0);
-        atomicAdd(tb + (size_t)i1 * F + f, g * wz1 * wy0 * wx1);
-        atomicAdd(tb + (size_t)i2 * F + f, g * wz1 * wy0 * wx0);
-        atomicAdd(tb + (size_t)i4 * F + f, g * wz0 * wy1 * wx1);
-        atomicAdd(tb + (size_t)i7 * F + f, g * wz0 * wy1 * wx0);
-        atomicAdd(tb + (size_t)i5 * F + f, g * wz0 * wy0 * wx1);
-        atomicAdd(tb + (size_t)i6 * F + f, g * wz0 * wy0 * wx0);
-      }
+      for (int i = 0; i < LG * F; ++i)
+        if (l0 + i / F < L) out[(m * L + l0) * F + i] = vals[i];
     }
   }
 }
@@ -154,9 +174,10 @@ static int launch_hashgrid(const float* x, int64_t M, const float* tables, float
   ResTab rt;
   for (int l = 0; l < L; ++l) rt.res[l] = (float)res[l];
   const uint32_t T = 1u << log2_T;
-  const dim3 g(grid_for(M * L, 256)), b(256);
+  constexpr int LG = 4;                                   // levels per thread: LG x F contiguous floats per sample
+  const dim3 g(grid_for(M, 256), (unsigned)((L + LG - 1) / LG)), b(256);
   auto st = as_stream(stream);
-#define HG(FF) hipLaunchKernelGGL((hashgrid_kernel<FF, BWD>), g, b, 0, st, x, M, tables, d_tables, d_out, L, T, rt, out)
+#define HG(FF) hipLaunchKernelGGL((hashgrid_kernel<FF, BWD, LG>), g, b, 0, st, x, M, tables, d_tables, d_out, L, T, rt, out)
   switch (F) { case 1: HG(1); break; case 2: HG(2); break; case 4: HG(4); break; default: HG(8); }
 #undef HG
   return check_launch(who);
