@@ -139,7 +139,12 @@ int nerf_mse_loss_grad(const float* pred, const float* target, int64_t count, fl
  * layer as weight[out][in] row-major followed by bias[out]  (nn.Linear: x @ W^T + b):
  *   pos0 [256x63] pos1..pos4 [256x256] pos5 [256x319] pos6 pos7 [256x256]
  *   feature [256x256]  alpha [1x256]  dir0 [128x283]  rgb [3x128]
- * Gradients use the same layout.                                                       */
+ * Gradients use the same layout.  Three instances of the class have kernels: the view
+ * model above, the image model {8, 256, 40, 0, 4, 0, out_ch <= 4}
+ * (entrypoints/__viser_image_learning.py:198-208) and the Instant-NGP-sized view model
+ * {2, 64, 32, 16, -1, 1}: pos0 [64x32] pos1 [64x64] feature [64x64] alpha [1x64]
+ * dir0 [32x80] rgb [3x32] = 13 188 parameters (forward / forward_train / backward on
+ * embedded rows; no fused positional-encoding query).                                  */
 typedef struct nerf_mlp_arch {
   int n_layers;     /* 8   */
   int width;        /* 256 */
@@ -180,6 +185,12 @@ int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, const float*
  * dz: scratch of nerf_mlp_dz_bytes(M); grads [param_count] is OVERWRITTEN.              */
 int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
                       int64_t M, void* dz, float* grads, void* stream);
+/* Same, and dL/d(position features) d_x [M, in_pos] for a trainable encoder in front of the network (the hash
+ * grid: nerf_hashgrid_backward takes it).  Only for the Instant-NGP-sized instance of the reference's NeRF class
+ * {n_layers 2, width 64, in_pos 32, in_dir 16, skip_layer -1, use_viewdirs 1} (BASELINE configs[4]); the 8 x 256
+ * models sit behind fixed encodings and return NERF_E_UNSUPPORTED.                                             */
+int nerf_mlp_backward_inputs(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
+                             int64_t M, void* dz, float* grads, float* d_x, void* stream);
 
 /* ---------------------------------------------------------------- fused renderer (a14 / a18)
  * replaces: rendering/render.py:164-241 render_rays_eval (coarse pass, importance sampling, sort, second pass)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "nerf_mlp_forward_train": (_I, [_P, _P, _P, _I64, _P, _P, _P]),
     "nerf_query_fused": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
     "nerf_mlp_backward": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P]),
+    "nerf_mlp_backward_inputs": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "nerf_render_workspace_bytes": (_I64, [_I64, _I, _I]),
     "nerf_render_rays_fused": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_comm_unique_id": (_I, [C.c_char_p]),

@@ -1576,6 +1576,212 @@ __global__ void __launch_bounds__(512, 2) mlp_img_bwd_ring_kernel(ImgArgs a) {
   ws.drain();
 }
 
+
+// ==========================================================================================
+// Third architecture: the reference's NeRF class at Instant-NGP size (BASELINE configs[4]: hash-grid features +
+// tiny MLP): NeRF(n_layers=2, width_layers=64, channel_input=32 [16 levels x 2 features], channel_input_views=16
+// [SH degree 3], list_skip_connection_layers=[], is_use_view_directions=True)  (models/NeRF.py:160-243):
+// pos0 [64x32] pos1 [64x64] feature [64x64] alpha [1x64] dir0 [32x80] rgb [3x32] = 13 188 parameters.
+// All 31 forward (27 backward) fragments fit LDS, so there is no ring: every workgroup copies its stream once and
+// its 8 waves then run independently over sample tiles.  Same register-resident chain, same fragment-block stores,
+// same dW kernel (7 jobs); the chain additionally returns dL/d(input features) for the hash-grid backward.
+// ==========================================================================================
+namespace LN {
+constexpr int CPOS = 32, CDIR = 16, CIN = CPOS + CDIR;
+constexpr int P_W0 = 0, P_B0 = 2048, P_W1 = 2112, P_B1 = 6208, P_WF = 6272, P_BF = 10368, P_WA = 10432, P_BA = 10496;
+constexpr int P_WD = 10497, P_BD = 13057, P_WR = 13089, P_BR = 13185, P_TOTAL = 13188;
+constexpr int F_L0 = 0, F_L1 = 4, F_FA = 12, F_DIR = 24, F_RGB = 29, F_TOTAL = 31, F_PADDED = 32;
+constexpr int B_RGB = 0, B_DIR = 1, B_FA = 5, B_L1 = 15, B_L0 = 23, B_TOTAL = 27, B_PADDED = 32;
+constexpr int BI_L0 = 0, BI_L1 = 64, BI_FEAT = 128, BI_ALPHA = 192, BI_DIR = 224, BI_RGB = 256, BI_TOTAL = 288;
+constexpr int64_t PACKED_BYTES = (int64_t)(F_PADDED + B_PADDED) * 1024 + BI_TOTAL * 4;
+constexpr int A_X = 0, A_DX = 2, A_H0 = 3, A_H1 = 7, A_FEAT = 11, A_HD = 15, A_MASK = 17, A_SLOTS = 20;
+constexpr int Z_L0 = 0, Z_L1 = 4, Z_F = 8, Z_A = 12, Z_D = 13, Z_RGB = 15, Z_SLOTS = 16;
+constexpr int LDS_BYTES = 32 * 1024 + BI_TOTAL * 4;
+}  // namespace LN
+
+__device__ float fwd_src_small(const float* __restrict__ p, int f, int r, int h, int j) {
+  if (f < LN::F_L1) { const int nt = f / 2, ks = f % 2; return p[LN::P_W0 + (32 * nt + r) * 32 + kperm(ks, h, j)]; }
+  if (f < LN::F_FA) { const int g = f - LN::F_L1, nt = g / 4, ks = g % 4; return p[LN::P_W1 + (32 * nt + r) * 64 + kperm(ks, h, j)]; }
+  if (f < LN::F_DIR) {
+    const int g = f - LN::F_FA;
+    if (g < 8) return p[LN::P_WF + (32 * (g / 4) + r) * 64 + kperm(g % 4, h, j)];
+    return r == 0 ? p[LN::P_WA + kperm(g - 8, h, j)] : 0.0f;
+  }
+  if (f < LN::F_RGB) { const int ks = f - LN::F_DIR; return p[LN::P_WD + r * 80 + kperm(ks, h, j)]; }      // [feature(64), sh(16)]
+  if (f < LN::F_TOTAL) return r < 3 ? p[LN::P_WR + r * 32 + kperm(f - LN::F_RGB, h, j)] : 0.0f;
+  return 0.0f;
+}
+// transposed stream: A rows = INPUT feature (32 kt + r), k index = OUTPUT feature nn
+__device__ float bwd_src_small(const float* __restrict__ p, int f, int r, int h, int j) {
+  if (f < LN::B_DIR) { const int nn = kperm(0, h, j); return nn < 3 ? p[LN::P_WR + nn * 32 + r] : 0.0f; }
+  if (f < LN::B_FA) { const int g = f - LN::B_DIR, kt = g / 2, ns = g % 2; return p[LN::P_WD + kperm(ns, h, j) * 80 + 32 * kt + r]; }
+  if (f < LN::B_L1) {
+    const int g = f - LN::B_FA, kt = g / 5, ns = g % 5, nn = kperm(ns, h, j);
+    if (ns < 4) return p[LN::P_WF + nn * 64 + 32 * kt + r];
+    return nn == 64 ? p[LN::P_WA + 32 * kt + r] : 0.0f;
+  }
+  if (f < LN::B_L0) { const int g = f - LN::B_L1, kt = g / 4, ns = g % 4; return p[LN::P_W1 + kperm(ns, h, j) * 64 + 32 * kt + r]; }
+  if (f < LN::B_TOTAL) return p[LN::P_W0 + kperm(f - LN::B_L0, h, j) * 32 + r];
+  return 0.0f;
+}
+__global__ void __launch_bounds__(256) pack_small_kernel(const float* __restrict__ p, bf16x8* __restrict__ wf,
+                                                         bf16x8* __restrict__ wb, float* __restrict__ bias) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int nf = LN::F_PADDED * 64, nb = LN::B_PADDED * 64;
+  if (tid < nf + nb) {
+    const bool fw = tid < nf;
+    const int t = fw ? tid : tid - nf, f = t >> 6, lane = t & 63, r = lane & 31, h = lane >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(fw ? fwd_src_small(p, f, r, h, j) : bwd_src_small(p, f, r, h, j));
+    (fw ? wf : wb)[t] = v;
+  } else if (tid < nf + nb + LN::BI_TOTAL) {
+    const int s = tid - nf - nb;
+    float v = 0.0f;
+    if (s < LN::BI_L1) v = p[LN::P_B0 + s];
+    else if (s < LN::BI_FEAT) v = p[LN::P_B1 + (s - LN::BI_L1)];
+    else if (s < LN::BI_ALPHA) v = p[LN::P_BF + (s - LN::BI_FEAT)];
+    else if (s < LN::BI_DIR) v = (s == LN::BI_ALPHA) ? p[LN::P_BA] : 0.0f;
+    else if (s < LN::BI_RGB) v = p[LN::P_BD + (s - LN::BI_DIR)];
+    else v = (s - LN::BI_RGB) < 3 ? p[LN::P_BR + (s - LN::BI_RGB)] : 0.0f;
+    bias[s] = v;
+  }
+}
+
+// weight source (3): the whole stream resident in LDS (copied once per workgroup)
+struct LdsW {
+  __device__ __forceinline__ bf16x8 frag(int f, int lane) { return *reinterpret_cast<const bf16x8*>(ring_smem + f * 1024 + lane * 16); }
+  __device__ __forceinline__ void note_stores(int) {}
+  __device__ __forceinline__ float4 bias4(int slot) { return *reinterpret_cast<const float4*>(ring_smem + 32 * 1024 + slot * 4); }
+};
+__device__ __forceinline__ void lds_load_stream(const bf16x8* __restrict__ w, const float* __restrict__ bias) {
+  for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) *reinterpret_cast<bf16x8*>(ring_smem + i * 16) = w[i];
+  if (bias)
+    for (int i = threadIdx.x; i < LN::BI_TOTAL; i += blockDim.x) *reinterpret_cast<float*>(ring_smem + 32 * 1024 + 4 * i) = bias[i];
+  __syncthreads();
+}
+
+struct SmallArgs {
+  const bf16x8* wf; const bf16x8* wb; const float* bias;
+  const float* x;        // [M,48]: 32 position features | 16 direction features
+  const float* d_raw;    // [M,4]
+  int64_t M;
+  float* out;            // [M,4] raw
+  float* d_x;            // [M,32] dL/d(position features) or nullptr
+  void* acts; void* dz;
+  int64_t astride, zstride;
+};
+
+template <bool STORE>
+__global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
+  constexpr int ST = 1;
+  lds_load_stream(a.wf, a.bias);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (a.M + 31) >> 5;
+  LdsW ws;
+  for (int64_t tile0 = (int64_t)blockIdx.x * 8 + wv; tile0 < ntiles; tile0 += (int64_t)gridDim.x * 8) {
+    int64_t m = tile0 * 32 + r; if (m >= a.M) m = a.M - 1;
+    const float* row = a.x + m * LN::CIN;
+    bf16x8 xin[ST][2], din[ST][1];
+    xin[0][0] = row_frag(row, 0, h, LN::CPOS); xin[0][1] = row_frag(row, 1, h, LN::CPOS);
+    din[0][0] = row_frag(row + LN::CPOS, 0, h, LN::CDIR);
+#define SINK(slot0) FragSink<STORE>{a.acts, tile0, a.astride, slot0, r, h}
+#define MASK_STORE(layer) do { if (STORE) *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0, a.astride, LN::A_MASK + (layer), r, h)) = mk[0]; } while (0)
+    if (STORE) { store_frags<2>(a.acts, tile0, a.astride, LN::A_X, xin[0], r, h); store_frags<1>(a.acts, tile0, a.astride, LN::A_DX, din[0], r, h); }
+    u32x4 mk[ST];
+    bf16x8 h0[ST][4], h1[ST][4], ft[ST][4];
+    mk[0] = u32x4{0u, 0u, 0u, 0u};
+    layer_fwd<ST, 2, 2, true, STORE>(ws, LN::F_L0, LN::BI_L0, xin, h0, mk, lane, SINK(LN::A_H0));
+    MASK_STORE(0);
+    mk[0] = u32x4{0u, 0u, 0u, 0u};
+    layer_fwd<ST, 4, 2, true, STORE>(ws, LN::F_L1, LN::BI_L1, h0, h1, mk, lane, SINK(LN::A_H1));
+    MASK_STORE(1);
+    layer_fwd<ST, 4, 2, false, false>(ws, LN::F_FA, LN::BI_FEAT, h1, ft, mk, lane, SINK(LN::A_FEAT));
+    float alpha;
+    {
+      f32x16 acc;
+      acc_init_bias(acc, ws, LN::BI_ALPHA, h);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws.frag(LN::F_FA + 8 + ks, lane), h1[0][ks], acc, 0, 0, 0);
+      alpha = acc[0];
+    }
+    bf16x8 hd[ST][2];
+    {
+      bf16x8 cat[ST][5];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cat[0][k] = ft[0][k];
+      cat[0][4] = din[0][0];
+      mk[0] = u32x4{0u, 0u, 0u, 0u};
+      layer_fwd<ST, 5, 1, true, STORE>(ws, LN::F_DIR, LN::BI_DIR, cat, hd, mk, lane, SINK(LN::A_HD));
+      MASK_STORE(2);
+    }
+    {
+      f32x16 acc;
+      acc_init_bias(acc, ws, LN::BI_RGB, h);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws.frag(LN::F_RGB + ks, lane), hd[0][ks], acc, 0, 0, 0);
+      const int64_t mo = tile0 * 32 + r;
+      if (h == 0 && mo < a.M) {
+        float4 o; o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = alpha;
+        *reinterpret_cast<float4*>(a.out + mo * 4) = o;
+      }
+    }
+#undef SINK
+#undef MASK_STORE
+  }
+}
+
+__global__ void __launch_bounds__(512) mlp_small_bwd_kernel(SmallArgs a) {
+  constexpr int ST = 1;
+  lds_load_stream(a.wb, nullptr);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (a.M + 31) >> 5;
+  LdsW ws;
+  for (int64_t tile0 = (int64_t)blockIdx.x * 8 + wv; tile0 < ntiles; tile0 += (int64_t)gridDim.x * 8) {
+    const int64_t m = tile0 * 32 + r;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < a.M && h == 0) g = *reinterpret_cast<const float4*>(a.d_raw + m * 4);
+    bf16x8 zrgb[ST][1], zal[ST][1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { zrgb[0][0][j] = (__bf16)0.0f; zal[0][0][j] = (__bf16)0.0f; }
+    zrgb[0][0][0] = (__bf16)g.x; zrgb[0][0][1] = (__bf16)g.y; zrgb[0][0][2] = (__bf16)g.z;
+    zal[0][0][0] = (__bf16)g.w;
+    u32x4 mk[3][ST];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+      mk[l][0] = *reinterpret_cast<const u32x4*>(frag_ptr(const_cast<void*>(a.acts), tile0, a.astride, LN::A_MASK + l, r, h));
+    store_frags<1>(a.dz, tile0, a.zstride, LN::Z_RGB, zrgb[0], r, h);
+    store_frags<1>(a.dz, tile0, a.zstride, LN::Z_A, zal[0], r, h);
+#define ZSINK(slot0) FragSink<true>{a.dz, tile0, a.zstride, slot0, r, h}
+    bf16x8 zd[ST][2], zf[ST][4], z1[ST][4], z0[ST][4];
+    layer_bwd<ST, 1, 1, true>(ws, LN::B_RGB, zrgb, zd, mk[2], lane, ZSINK(LN::Z_D));
+    layer_bwd<ST, 2, 2, false>(ws, LN::B_DIR, zd, zf, mk[2], lane, ZSINK(LN::Z_F));               // d feature
+    {
+      bf16x8 cat[ST][5];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cat[0][k] = zf[0][k];
+      cat[0][4] = zal[0][0];
+      layer_bwd<ST, 5, 2, true>(ws, LN::B_FA, cat, z1, mk[1], lane, ZSINK(LN::Z_L1));              // dZ1
+    }
+    layer_bwd<ST, 4, 2, true>(ws, LN::B_L1, z1, z0, mk[0], lane, ZSINK(LN::Z_L0));                 // dZ0
+#undef ZSINK
+    if (a.d_x) {                                          // dL/dx = W0^T dZ0, kept in fp32: rows (i&3) + 8 (i>>2) + 4 h
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws.frag(LN::B_L0 + ns, lane), z0[0][ns], acc, 0, 0, 0);
+      if (m < a.M) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 o; o.x = acc[4 * q]; o.y = acc[4 * q + 1]; o.z = acc[4 * q + 2]; o.w = acc[4 * q + 3];
+          *reinterpret_cast<float4*>(a.d_x + m * LN::CPOS + 8 * q + 4 * h) = o;
+        }
+      }
+    }
+  }
+}
+
 static int g_dw_wgs = 0;       // 0: automatic (see launch_dw)
 static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW only (on whatever dz holds)
 static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
@@ -1591,9 +1797,12 @@ static void ensure_lds(K kernel, int bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-// 0: the NeRF view model (63+27 -> 4), 1: the image-fitting model (40 -> out_ch), -1: no HIP kernel
+// 0: the NeRF view model (63+27 -> 4), 1: the image-fitting model (40 -> out_ch), 2: the Instant-NGP-sized view
+// model (32+16 -> 4, 2 x 64), -1: no HIP kernel
 static int arch_kind(const nerf_mlp_arch* a) {
-  if (!a || a->n_layers != 8 || a->width != 256 || a->skip_layer != 4) return -1;
+  if (!a) return -1;
+  if (a->n_layers == 2 && a->width == 64 && a->skip_layer < 0 && a->use_viewdirs == 1 && a->in_pos == 32 && a->in_dir == 16) return 2;
+  if (a->n_layers != 8 || a->width != 256 || a->skip_layer != 4) return -1;
   if (a->use_viewdirs == 1 && a->in_pos == 63 && a->in_dir == 27) return 0;
   if (a->use_viewdirs == 0 && a->in_pos == 40 && a->out_ch >= 1 && a->out_ch <= 4) return 1;
   return -1;
@@ -1602,6 +1811,8 @@ static bool arch_ok(const nerf_mlp_arch* a) { return arch_kind(a) == 0; }
 static inline int64_t img_astride16() { return (int64_t)LI::A_SLOTS * 64 + g_tile_pad16; }
 static inline int64_t img_zstride16() { return (int64_t)LI::Z_SLOTS * 64 + g_tile_pad16; }
 static inline int64_t img_params(const nerf_mlp_arch* a) { return LI::P_WO + (int64_t)a->out_ch * 257; }
+static inline int64_t small_astride16() { return (int64_t)LN::A_SLOTS * 64 + g_tile_pad16; }
+static inline int64_t small_zstride16() { return (int64_t)LN::Z_SLOTS * 64 + g_tile_pad16; }
 
 }  // namespace nerf
 
@@ -1620,25 +1831,25 @@ extern "C" int nerf_set_option(const char* key, int value) {
 
 extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
-  return k == 0 ? L::P_TOTAL : k == 1 ? img_params(arch) : -1;
+  return k == 0 ? L::P_TOTAL : k == 1 ? img_params(arch) : k == 2 ? LN::P_TOTAL : -1;
 }
 extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
-  return k == 0 ? L::PACKED_BYTES : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : -1;
+  return k == 0 ? L::PACKED_BYTES : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
 }
 static inline int64_t padded_tiles(int64_t M) { return (((M + 31) / 32) + 7) / 8 * 8; }
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
-  return padded_tiles(M) * (k == 0 ? astride16() : img_astride16()) * 16;
+  return padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16() : small_astride16()) * 16;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
-  return padded_tiles(M) * (k == 0 ? zstride16() : img_zstride16()) * 16;
+  return padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16;
 }
 
-#define NERF_ARCH_MSG ": HIP kernels exist for (8x256, skip 4) with in=63+27 view head, or in=40 / no view head / out_ch<=4"
+#define NERF_ARCH_MSG ": HIP kernels exist for (8x256, skip 4) with in=63+27 view head, or in=40 / no view head / out_ch<=4, and for (2x64, no skip) with in=32+16 view head"
 #define NERF_ARCH_CHECK(who) NERF_REQUIRE(arch_ok(arch), NERF_E_UNSUPPORTED, who NERF_ARCH_MSG)
 #define NERF_ARCH_CHECK_ANY(who) NERF_REQUIRE(arch_kind(arch) >= 0, NERF_E_UNSUPPORTED, who NERF_ARCH_MSG)
 
@@ -1646,6 +1857,13 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
   NERF_ARCH_CHECK_ANY("nerf_mlp_pack");
   NERF_REQUIRE(params && packed, NERF_E_NULL, "nerf_mlp_pack: params/packed is NULL");
   char* base = static_cast<char*>(packed);
+  if (arch_kind(arch) == 2) {
+    const int tot = (LN::F_PADDED + LN::B_PADDED) * 64 + LN::BI_TOTAL;
+    hipLaunchKernelGGL(pack_small_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), params,
+                       reinterpret_cast<bf16x8*>(base), reinterpret_cast<bf16x8*>(base + (size_t)LN::F_PADDED * 1024),
+                       reinterpret_cast<float*>(base + (size_t)(LN::F_PADDED + LN::B_PADDED) * 1024));
+    return check_launch("nerf_mlp_pack (2x64 model)");
+  }
   if (arch_kind(arch) == 1) {
     bf16x8* wfi = reinterpret_cast<bf16x8*>(base);
     bf16x8* wbi = reinterpret_cast<bf16x8*>(base + (size_t)LI::F_TOTAL * 1024);
@@ -1730,11 +1948,30 @@ static void img_args(ImgArgs& a, const nerf_mlp_arch* arch, const void* packed) 
   a.x = nullptr; a.d_out = nullptr; a.out = nullptr; a.acts = nullptr; a.dz = nullptr; a.M = 0;
 }
 
+static void small_args(SmallArgs& a, const void* packed) {
+  const char* base = static_cast<const char*>(packed);
+  a.wf = reinterpret_cast<const bf16x8*>(base);
+  a.wb = reinterpret_cast<const bf16x8*>(base + (size_t)LN::F_PADDED * 1024);
+  a.bias = reinterpret_cast<const float*>(base + (size_t)(LN::F_PADDED + LN::B_PADDED) * 1024);
+  a.x = nullptr; a.d_raw = nullptr; a.out = nullptr; a.d_x = nullptr; a.acts = nullptr; a.dz = nullptr; a.M = 0;
+  a.astride = small_astride16(); a.zstride = small_zstride16();
+}
+
 extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M,
                                       float* out, void* acts, void* stream) {
   NERF_ARCH_CHECK_ANY("nerf_mlp_forward");
   if (M <= 0) return NERF_OK;
   NERF_REQUIRE(packed && x && out, NERF_E_NULL, "nerf_mlp_forward: NULL pointer");
+  if (arch_kind(arch) == 2) {
+    SmallArgs a;
+    small_args(a, packed);
+    a.x = x; a.out = out; a.acts = acts; a.M = M;
+    const int64_t nwg = ((M + 31) / 32 + 7) / 8;
+    const dim3 g((unsigned)(nwg < 2048 ? nwg : 2048)), b(512);
+    if (acts) hipLaunchKernelGGL(mlp_small_fwd_kernel<true>, g, b, LN::LDS_BYTES, as_stream(stream), a);
+    else hipLaunchKernelGGL(mlp_small_fwd_kernel<false>, g, b, LN::LDS_BYTES, as_stream(stream), a);
+    return check_launch("mlp forward (2x64 model)");
+  }
   if (arch_kind(arch) == 1) {
     ImgArgs a;
     img_args(a, arch, packed);
@@ -1810,13 +2047,37 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   return check_launch("mlp dW");
 }
 
-extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
-                                 int64_t M, void* dz, float* grads, void* stream) {
+static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
+                             int64_t M, void* dz, float* grads, float* d_x, void* stream) {
   NERF_ARCH_CHECK_ANY("nerf_mlp_backward");
+  NERF_REQUIRE(!d_x || arch_kind(arch) == 2, NERF_E_UNSUPPORTED,
+               "nerf_mlp_backward_inputs: input gradients exist for the (2x64) model only (the 8x256 models take fixed encodings)");
   NERF_REQUIRE(packed && acts && d_raw && dz && grads, NERF_E_NULL, "nerf_mlp_backward: NULL pointer");
   NERF_REQUIRE(M > 0, NERF_E_SHAPE, "nerf_mlp_backward: M must be > 0");
   auto s = as_stream(stream);
   const int64_t ntiles = (M + 31) / 32;
+  if (arch_kind(arch) == 2) {
+    SmallArgs a;
+    small_args(a, packed);
+    a.d_raw = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M; a.d_x = d_x;
+    const int64_t nwg = (ntiles + 7) / 8;
+    hipLaunchKernelGGL(mlp_small_bwd_kernel, dim3((unsigned)(nwg < 2048 ? nwg : 2048)), dim3(512), LN::LDS_BYTES, s, a);
+    int rcs = check_launch("mlp backward chain (2x64 model)");
+    if (rcs) return rcs;
+    DwArgs ds;
+    int njs = 0;
+    auto jobs = [&](int dz_slot, int nf, int act_slot, int kf, int w_off, int ldw, int col0, int nv, int kv, int b_off) {
+      ds.jobs[njs++] = DwJob{dz_slot, nf, act_slot, kf, w_off, ldw, col0, nv, kv, b_off};
+    };
+    jobs(LN::Z_L0, 4, LN::A_X, 2, LN::P_W0, 32, 0, 64, 32, LN::P_B0);          // pos0
+    jobs(LN::Z_L1, 4, LN::A_H0, 4, LN::P_W1, 64, 0, 64, 64, LN::P_B1);         // pos1
+    jobs(LN::Z_F, 4, LN::A_H1, 4, LN::P_WF, 64, 0, 64, 64, LN::P_BF);          // feature
+    jobs(LN::Z_A, 1, LN::A_H1, 4, LN::P_WA, 64, 0, 1, 64, LN::P_BA);           // alpha
+    jobs(LN::Z_D, 2, LN::A_FEAT, 4, LN::P_WD, 80, 0, 32, 64, LN::P_BD);        // dir0 | feature
+    jobs(LN::Z_D, 2, LN::A_DX, 1, LN::P_WD, 80, 64, 32, 16, -1);               // dir0 | direction features
+    jobs(LN::Z_RGB, 1, LN::A_HD, 2, LN::P_WR, 32, 0, 3, 32, LN::P_BR);         // rgb
+    return launch_dw(ds, njs, ntiles, LN::P_TOTAL, acts, dz, small_astride16(), small_zstride16(), grads, s);
+  }
   if (arch_kind(arch) == 1) {
     ImgArgs a;
     img_args(a, arch, packed);
@@ -1884,6 +2145,18 @@ extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, 
   job(L::Z_D, 8, L::A_DPE, 2, L::P_WD, 283, 256, 128, 27, -1);                                     // dir0 | dirPE
   job(L::Z_RGB, 1, L::A_HD, 8, L::P_WR, 128, 0, 3, 128, L::P_BR);                                  // rgb
   return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astride16(), zstride16(), grads, s);
+}
+
+extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
+                                 int64_t M, void* dz, float* grads, void* stream) {
+  return mlp_backward_impl(arch, packed, acts, d_raw, M, dz, grads, nullptr, stream);
+}
+
+extern "C" int nerf_mlp_backward_inputs(const nerf_mlp_arch* arch, const void* packed, const void* acts,
+                                        const float* d_raw, int64_t M, void* dz, float* grads, float* d_x,
+                                        void* stream) {
+  NERF_REQUIRE(d_x, NERF_E_NULL, "nerf_mlp_backward_inputs: d_x is NULL");
+  return mlp_backward_impl(arch, packed, acts, d_raw, M, dz, grads, d_x, stream);
 }
 
 #ifdef NERF_CLOCK_STAMP

@@ -98,7 +98,8 @@ class NeRF:
             nbytes = lib.nerf_mlp_packed_bytes(C.byref(self.arch))
             if nbytes < 0:
                 raise ValueError("libnerf_hip error -3: this NeRF architecture has no HIP kernel (supported: n_layers=8, "
-                                 "width=256, skips=[4] with in=63+27 + view head, or in=40 without view head and out<=4)")
+                                 "width=256, skips=[4] with in=63+27 + view head, or in=40 without view head and out<=4; n_layers=2, "
+                                 "width=64, skips=[] with in=32+16 + view head)")
             self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         if self._dirty:
             N.check(lib.nerf_mlp_pack(C.byref(self.arch), N.ptr(self.params), N.ptr(self._packed), N.stream()))
@@ -141,12 +142,19 @@ class NeRF:
                                          0 if ref_quirks else 1, N.ptr(raw), N.ptr(acts), N.stream()))
         return raw
 
-    def backward(self, d_raw: torch.Tensor) -> torch.Tensor:
-        """Parameter gradients of the last `query(..., train=True)`; overwrites self.grads."""
+    def backward(self, d_raw: torch.Tensor, need_input_grad: bool = False):
+        """Parameter gradients of the last `query / forward(..., train=True)`; overwrites self.grads.
+        need_input_grad (2 x 64 model only): also returns dL/d(position features) [M, channel_input] for a trainable
+        encoder in front of the network (the hash grid)."""
         d_raw = N.f32(d_raw)
         M = d_raw.numel() // self.out_dim
         assert M == getattr(self, "_acts_M", -1), "backward() needs a matching query/forward(train=True) first"
         dz = self._workspace("dz", N.lib().nerf_mlp_dz_bytes(C.byref(self.arch), M))
+        if need_input_grad:
+            d_x = torch.empty(M, self.channel_input_pos, dtype=torch.float32, device=d_raw.device)
+            N.check(N.lib().nerf_mlp_backward_inputs(C.byref(self.arch), N.ptr(self.packed()), N.ptr(self._ws["acts"]),
+                                                     N.ptr(d_raw), M, N.ptr(dz), N.ptr(self.grads), N.ptr(d_x), N.stream()))
+            return self.grads, d_x
         N.check(N.lib().nerf_mlp_backward(C.byref(self.arch), N.ptr(self.packed()), N.ptr(self._ws["acts"]),
                                           N.ptr(d_raw), M, N.ptr(dz), N.ptr(self.grads), N.stream()))
         return self.grads

@@ -551,6 +551,63 @@ def test_image_model_forward_backward():
     assert off == 482051
 
 
+# ------------------------------------------------------------------------------ configs[4]: Instant-NGP-sized model
+def _small_pair(scale=1.5):
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    arch = O.NerfArch(channel_input=32, channel_input_views=16, n_layers=2, width=64, skips=(), use_viewdirs=True)
+    m = NeRF(n_layers=2, width_layers=64, channel_input=32, channel_input_views=16, list_skip_connection_layers=[],
+             is_use_view_directions=True, device=DEV, seed=0)
+    assert m.n_params == 13188 == arch.n_params()
+    flat = O.flatten_params(arch, O.init_params(arch, 0)) * scale
+    m.load_flat(flat)
+    return m, arch, flat
+
+
+def test_small_model_forward_backward_and_input_grads():
+    """NeRF(n_layers=2, width=64, in 32+16, view head): forward, dW/db and dL/d(position features) vs autograd
+    through the bf16-emulating oracle (ragged M: 1, 33, 4100 samples)."""
+    m, arch, flat = _small_pair()
+    p = O.unflatten_params(arch, flat)
+    torch.manual_seed(21)
+    for M in (1, 33, 4100):
+        x = torch.randn(M, 48)
+        got = m.forward(x.to(DEV)).cpu()
+        assert got.shape == (M, 4)
+        assert _relmax(got, O.nerf_forward(arch, p, x, emulate_bf16=True)) < 1e-2
+        assert _relmax(got, O.nerf_forward(arch, p, x)) < 3e-2
+    M = 4100
+    x = torch.randn(M, 48); g = torch.randn(M, 4)
+    out = m.forward(x.to(DEV), train=True)
+    grads, d_x = m.backward(g.to(DEV), need_input_grad=True)
+    grads, d_x = grads.cpu(), d_x.cpu()
+    fl = flat.clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    want_out = O.nerf_forward(arch, O.unflatten_params(arch, fl), xr, emulate_bf16=True)
+    (want_out * g).sum().backward()
+    assert _relmax(out.cpu(), want_out.detach()) < 1e-2
+    off = 0
+    for name, o_, i_ in arch.layer_shapes():
+        for part, cnt in (("W", o_ * i_), ("b", o_)):
+            a, b = grads[off:off + cnt], fl.grad[off:off + cnt]
+            assert _rel_l2(a, b) < 2e-2 and _relmax(a, b) < 1.2e-1, (name, part, _rel_l2(a, b), _relmax(a, b))
+            off += cnt
+    assert off == 13188
+    assert d_x.shape == (M, 32)
+    assert _rel_l2(d_x, xr.grad[:, :32]) < 2e-2, _rel_l2(d_x, xr.grad[:, :32])
+    # the gradient without input grads is the same parameter gradient
+    m.forward(x.to(DEV), train=True)
+    assert torch.equal(m.backward(g.to(DEV)).cpu(), grads) or _rel_l2(m.grads.cpu(), grads) < 1e-5
+
+
+def test_input_grads_refused_for_the_large_models():
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=0)
+    x = torch.randn(64, 90, device=DEV)
+    m.forward(x, train=True)
+    with pytest.raises((RuntimeError, ValueError)):
+        m.backward(torch.randn(64, 4, device=DEV), need_input_grad=True)
+
+
 def test_image_fitter_tracks_oracle_loop():
     """entrypoints/__viser_image_learning.py loop, headless: same integer-coordinate batches through the HIP
     ImageFitter and the oracle loop; losses track (3 % for 2 steps, 12 % for the next 4) and the fit improves."""
