@@ -1,0 +1,115 @@
+"""BASELINE configs[4]: multiresolution hash-grid encoding + tiny fused MLP.
+
+The reference ships the pieces but never wires them (`encoding/multi_hash.py` cannot run, SURVEY Q13;
+`encoding/spherical_harmonics.py` has no caller): this module is that wiring, with the reference's own classes --
+`MultiHashEncoding(3, 16, 16, 2048, 2, 19)` for positions, `SphericalHarmonicsEncoding(3, 3)` for view directions,
+and its `NeRF` class at Instant-NGP size (`NeRF(n_layers=2, width_layers=64, channel_input=32,
+channel_input_views=16, list_skip_connection_layers=[], is_use_view_directions=True)`, models/NeRF.py:160-243) --
+trained by the coarse-only loop of `render_rays` (rendering/render.py:112-162) + `raw2outputs` + MSE + Adam.
+
+Device work: nerf_hashgrid_forward / nerf_sh_encode -> nerf_mlp_forward_train (2 x 64 kernels) ->
+nerf_composite_forward -> nerf_mse_loss_grad -> nerf_composite_backward -> nerf_mlp_backward_inputs (dZ chain, dW,
+dL/dfeatures) -> nerf_hashgrid_backward (float atomics) -> nerf_adam_step x 2.  torch only concatenates the two
+feature blocks and forms o + z d.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from .. import parallel, sampling
+from ..encoding.multi_hash import MultiHashEncoding
+from ..encoding.spherical_harmonics import SphericalHarmonicsEncoding
+from ..models.NeRF import Adam, NeRF
+from ..ops.metric import mse_loss_grad
+from ..rendering import render
+from .trainer import Trainer
+
+
+class _Flat:
+    """Adam-compatible view of a flat trainable buffer (the hash tables)."""
+
+    def __init__(self, params: torch.Tensor, grads: torch.Tensor):
+        self.params, self.grads, self.n_params = params.view(-1), grads.view(-1), params.numel()
+
+    def mark_updated(self):
+        pass
+
+
+class HashNeRF:
+    """positions -> hash grid (32) | view directions -> SH degree 3 (16) -> NeRF 2 x 64 -> raw [rgb, sigma]."""
+
+    def __init__(self, device="cuda", seed: int = 0, n_levels: int = 16, min_res: int = 16, max_res: int = 2048,
+                 n_features_per_level: int = 2, log2_hashmap_size: int = 19, hash_init_scale: float = 1e-4):
+        assert n_levels * n_features_per_level == 32, "the 2 x 64 kernels take 32 position features"
+        self.enc = MultiHashEncoding(3, n_levels, min_res, max_res, n_features_per_level, log2_hashmap_size,
+                                     hash_init_scale, device=device, seed=seed)
+        self.sh = SphericalHarmonicsEncoding(3, 3)
+        self.mlp = NeRF(n_layers=2, width_layers=64, channel_input=32, channel_input_views=16,
+                        list_skip_connection_layers=[], is_use_view_directions=True, device=device, seed=seed)
+        self.table = _Flat(self.enc.tables, self.enc.grad)
+        self._pts = None
+
+    def features(self, rays: torch.Tensor, z: torch.Tensor):
+        B, n = z.shape
+        pts = (rays[:, None, 0:3] + z[:, :, None] * rays[:, None, 3:6]).reshape(-1, 3)     # render.py:142
+        feat = self.enc(pts)                                                               # [B n, 32]
+        shf = self.sh(rays[:, 8:11].contiguous())                                          # [B, 16]
+        x = torch.cat([feat.view(B, n, 32), shf[:, None, :].expand(B, n, 16)], dim=-1).reshape(B * n, 48)
+        return pts, x
+
+    def query(self, rays: torch.Tensor, z: torch.Tensor, train: bool = False) -> torch.Tensor:
+        pts, x = self.features(rays, z)
+        if train:
+            self._pts = pts
+        return self.mlp.forward(x, train=train).view(z.shape[0], z.shape[1], 4)
+
+    def backward(self, d_raw: torch.Tensor):
+        """(MLP gradient [13188], table gradient [L,T,F]) of the last query(train=True)."""
+        grads, d_x = self.mlp.backward(d_raw, need_input_grad=True)
+        self.enc.grad.zero_()
+        self.enc.backward(self._pts, d_x)
+        return grads, self.enc.grad
+
+
+class NGPTrainer(Trainer):
+    """Coarse-only training / rendering loop on a HashNeRF (one network, `n_depth_samples` stratified-grid samples per
+    ray, no importance pass).  Rays shard across ranks; MLP and table gradients are sum-all-reduced before Adam."""
+
+    def __init__(self, images, poses, K, near: float = 2.0, far: float = 6.0, N_rand: int = 4096,
+                 n_depth_samples: int = 64, lrate: float = 1e-2, lrate_decay: int = 500, white_bkgd: bool = True,
+                 seed: int = 0, device="cuda", chunk: int = 1024 * 32, **hash_kw):
+        super().__init__(images, poses, K, near=near, far=far, N_rand=N_rand, n_depth_samples=n_depth_samples,
+                         N_importance=0, lrate=lrate, lrate_decay=lrate_decay, white_bkgd=white_bkgd, ref_quirks=True,
+                         seed=seed, device=device, chunk=chunk)
+        self.coarse = None                                   # the 8 x 256 network of the base class is not used
+        self.field = HashNeRF(device=self.device, seed=seed, **hash_kw)
+        self.opt = Adam(lrate, betas=(0.9, 0.99), eps=1e-15, shared_state=False)
+
+    def train_step(self, rays=None, target=None, u=None) -> Dict[str, torch.Tensor]:
+        if rays is None:
+            rays, target = self.sample_batch()
+        self.opt.learning_rate = self.lrate * (0.1 ** (self.it / (self.lrate_decay * 1000)))
+        z = sampling.sample_coarse(rays, self.n)
+        raw = self.field.query(rays, z, train=True)
+        rgb, _, _, _, _ = render.composite(raw, z, rays, 0.0, self.white_bkgd)
+        loss, d_rgb = mse_loss_grad(rgb, target)
+        d_raw = render.composite_backward(raw, z, rays, d_rgb, self.white_bkgd)
+        g_mlp, g_tab = self.field.backward(d_raw)
+        parallel.allreduce_sum_(g_mlp)
+        parallel.allreduce_sum_(g_tab.view(-1))
+        self.opt.update(self.field.mlp, g_mlp, grad_scale=1.0 / self.world)
+        self.opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world)
+        self.it += 1
+        return {"loss_coarse": loss}
+
+    def render_rays(self, rays: torch.Tensor, u=None):
+        outs = []
+        for s in range(0, rays.shape[0], self.chunk):
+            r = rays[s:s + self.chunk]
+            z = sampling.sample_coarse(r, self.n)
+            raw = self.field.query(r, z)
+            outs.append(render.composite(raw, z, r, 0.0, self.white_bkgd, need_weights=False)[0])
+        return torch.cat(outs, 0)
+
+    def state_dict(self):
+        return {"it": self.it, "mlp": self.field.mlp.params.cpu(), "tables": self.field.enc.tables.cpu()}

@@ -617,3 +617,54 @@ class OracleImageFitter:
         with torch.no_grad():
             adam_step(self.p, g, self.m, self.v, self.lr, b1=0.9, b2=0.99)
         return float(loss.detach()), g
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE configs[4]: hash grid + SH + the NeRF class at 2 x 64 (coarse-only loop)
+# --------------------------------------------------------------------------------------
+
+class OracleNGP:
+    """MultiHashEncoding(3,L,Nmin,Nmax,F,log2T) (encoding/multi_hash.py, intended semantics) for positions,
+    SphericalHarmonicsEncoding(3,3) for view directions, NeRF(n_layers=2, width=64, in 32+16, view head)
+    (models/NeRF.py:160-243), render_rays' coarse pass (rendering/render.py:112-162) + raw2outputs + MSE, Adam without
+    bias correction on the MLP and on the tables.  Tables are initialised by the caller (same values as the device)."""
+
+    def __init__(self, tables: torch.Tensor, resolutions, seed=0, n_samples=64, lrate=1e-2, lrate_decay=500,
+                 betas=(0.9, 0.99), eps=1e-15, emulate_bf16=False, near=2.0, far=6.0, white_bkgd=True):
+        self.arch = NerfArch(channel_input=32, channel_input_views=16, n_layers=2, width=64, skips=(), use_viewdirs=True)
+        self.p = flatten_params(self.arch, init_params(self.arch, seed)).requires_grad_(True)
+        self.tables = tables.clone().float().requires_grad_(True)
+        self.res = list(resolutions)
+        self.n, self.lrate, self.decay, self.lr = n_samples, lrate, lrate_decay, lrate
+        self.betas, self.eps, self.emu = betas, eps, emulate_bf16
+        self.near, self.far, self.white = near, far, white_bkgd
+        self.mp = [torch.zeros_like(self.p), torch.zeros_like(self.p)]
+        self.mt = [torch.zeros_like(self.tables), torch.zeros_like(self.tables)]
+        self.it = 0
+
+    def render(self, rays):
+        o, d, near, far, viewdirs = decompose_ray_batch(rays)
+        z = sample_z_uniform(near, far, self.n)
+        pts = o[..., None, :] + d[..., None, :] * z[..., :, None]
+        B, n = z.shape
+        feat = hashgrid_encoding(pts.reshape(-1, 3), self.tables, self.res).reshape(B, n, -1)
+        shf = sh_encoding(viewdirs, 3)
+        x = torch.cat([feat, shf[:, None, :].expand(B, n, shf.shape[-1])], -1).reshape(B * n, -1)
+        raw = nerf_forward(self.arch, unflatten_params(self.arch, self.p), x, self.emu).reshape(B, n, 4)
+        rgb, *_ = raw2outputs(raw, z, d, 0.0, white_bkgd=self.white)
+        return rgb
+
+    def loss_and_grads(self, rays_o, rays_d, target):
+        rays = pack_rays(rays_o, rays_d, self.near, self.far)
+        loss = mse(self.render(rays), target)
+        gp, gt = torch.autograd.grad(loss, [self.p, self.tables])
+        return loss.detach(), gp, gt
+
+    def step(self, rays_o, rays_d, target):
+        loss, gp, gt = self.loss_and_grads(rays_o, rays_d, target)
+        with torch.no_grad():
+            adam_step(self.p, gp, self.mp[0], self.mp[1], self.lr, self.betas[0], self.betas[1], self.eps)
+            adam_step(self.tables, gt, self.mt[0], self.mt[1], self.lr, self.betas[0], self.betas[1], self.eps)
+        self.it += 1
+        self.lr = lr_schedule(self.lrate, self.decay, self.it)
+        return float(loss)

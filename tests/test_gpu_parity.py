@@ -599,6 +599,48 @@ def test_small_model_forward_backward_and_input_grads():
     assert torch.equal(m.backward(g.to(DEV)).cpu(), grads) or _rel_l2(m.grads.cpu(), grads) < 1e-5
 
 
+def test_ngp_field_gradients_and_training_track_oracle():
+    """configs[4]: hash grid (small tables so that autograd on the oracle is cheap) + SH + 2 x 64 MLP.  One batch:
+    loss, MLP gradient and table gradient vs autograd through the bf16-emulating oracle; then 6 Adam iterations on
+    identical batches: losses track and fall."""
+    from nerf_meets_mlx_amd.engine.ngp import NGPTrainer
+    from nerf_meets_mlx_amd.dataset import synthetic
+    H = W = 32
+    imgs, poses, _, hwf, K = synthetic.make_dataset(H, W, 2, seed=0, device=DEV)
+    kw = dict(n_levels=16, min_res=4, max_res=128, n_features_per_level=2, log2_hashmap_size=12, hash_init_scale=0.5)
+    tr = NGPTrainer(imgs, poses, K, N_rand=256, n_depth_samples=32, seed=0, device=DEV, **kw)
+    orc = O.OracleNGP(tr.field.enc.tables.cpu(), tr.field.enc.scaled_res, seed=0, n_samples=32, emulate_bf16=True)
+    assert torch.equal(tr.field.mlp.params.cpu(), orc.p.detach())
+    rays, target = tr.sample_batch()
+    ro, rd, tg = rays[:, 0:3].cpu(), rays[:, 3:6].cpu(), target.cpu()
+    # --- gradients of one batch (no update)
+    from nerf_meets_mlx_amd import sampling
+    from nerf_meets_mlx_amd.rendering import render
+    from nerf_meets_mlx_amd.ops.metric import mse_loss_grad
+    z = sampling.sample_coarse(rays, 32)
+    raw = tr.field.query(rays, z, train=True)
+    rgb = render.composite(raw, z, rays, 0.0, True)[0]
+    loss, d_rgb = mse_loss_grad(rgb, target)
+    g_mlp, g_tab = tr.field.backward(render.composite_backward(raw, z, rays, d_rgb, True))
+    lo, gp, gt = orc.loss_and_grads(ro, rd, tg)
+    assert abs(float(loss) - float(lo)) < 2e-2 * float(lo), (float(loss), float(lo))
+    assert _rel_l2(g_mlp.cpu(), gp) < 5e-2, _rel_l2(g_mlp.cpu(), gp)
+    assert _rel_l2(g_tab.cpu(), gt) < 5e-2, _rel_l2(g_tab.cpu(), gt)
+    # --- a few iterations on identical batches
+    hip, ora = [], []
+    for it in range(6):
+        rays, target = tr.sample_batch()
+        hip.append(float(tr.train_step(rays, target)["loss_coarse"]))
+        ora.append(orc.step(rays[:, 0:3].cpu(), rays[:, 3:6].cpu(), target.cpu()))
+    for a, b in zip(hip[:2], ora[:2]):
+        assert abs(a - b) < 5e-2 * b, (hip, ora)
+    for a, b in zip(hip, ora):
+        assert abs(a - b) < 0.25 * b, (hip, ora)
+    assert hip[-1] < hip[0]
+    img = tr.render_frame(poses[0], shard=False)
+    assert img.shape == (H, W, 3) and torch.isfinite(img).all()
+
+
 def test_input_grads_refused_for_the_large_models():
     from nerf_meets_mlx_amd.models.NeRF import NeRF
     m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=0)
