@@ -48,6 +48,7 @@ class HashNeRF:
                         list_skip_connection_layers=[], is_use_view_directions=True, device=device, seed=seed)
         self.table = _Flat(self.enc.tables, self.enc.grad)
         self._pts = None
+        self.timing = None                  # bench.py: list that receives (start, end) events around the table scatter
 
     def features(self, rays: torch.Tensor, z: torch.Tensor):
         B, n = z.shape
@@ -67,7 +68,13 @@ class HashNeRF:
         """(MLP gradient [13188], table gradient [L,T,F]) of the last query(train=True)."""
         grads, d_x = self.mlp.backward(d_raw, need_input_grad=True)
         self.enc.grad.zero_()
+        if self.timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         self.enc.backward(self._pts, d_x)
+        if self.timing is not None:
+            e1.record()
+            self.timing.append((e0, e1))
         return grads, self.enc.grad
 
 

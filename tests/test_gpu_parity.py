@@ -212,6 +212,13 @@ def test_hashgrid_forward_backward():
     O.hashgrid_encoding(x.double(), t2, enc2.scaled_res).backward(g.double())
     got = enc2.backward(x.to(DEV), g.to(DEV)).cpu()
     np.testing.assert_allclose(got.numpy(), t2.grad.float().numpy(), rtol=2e-4, atol=2e-4)
+    # many points, 16 levels, heavy collisions in a 2^10 table: every contribution must arrive
+    enc3 = MultiHashEncoding(3, 16, 4, 256, 2, 10, device=DEV)
+    xs = torch.rand(300000, 3) * 3 - 1.5
+    g3 = torch.ones(300000, 32)
+    got3 = enc3.backward(xs.to(DEV), g3.to(DEV)).cpu().double()
+    # with unit upstream gradients every level's table receives sum of interpolation weights = number of points
+    np.testing.assert_allclose(got3.sum(dim=(1, 2)).numpy(), np.full(16, 2 * 300000.0), rtol=1e-4)
 
 
 # ------------------------------------------------------------------------------ a13
