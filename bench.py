@@ -244,7 +244,7 @@ def bench_ngp(args, imgs, poses, rposes, K, rank, world, dev):
                    "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
         "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
         "loss_coarse": float(out["loss_coarse"]),
-        "roofline": {"bound": "hbm", "kernel": "hashgrid_kernel<2, true, 4> (table gradient scatter, float atomics)",
+        "roofline": {"bound": "hbm", "kernel": "hashgrid_bwd_kernel<2, 4> (table gradient scatter, float atomics)",
                      "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes": alg,
                      "ms_per_launch": k_ms, "samples_per_launch": M,

@@ -108,6 +108,13 @@ int nerf_hashgrid_forward(const float* x, int64_t M, const float* tables, int L,
 int nerf_hashgrid_backward(const float* x, int64_t M, const float* d_out, int L, int log2_T, int F,
                            const int* resolutions_host, float* d_tables, void* stream);
 
+/* One input row per sample for the hash-grid model (BASELINE configs[4]; engine glue the reference never wrote):
+ * x_out [B n, L F + (sh_degree+1)^2] = [ hash features of o + z d | SH of the ray's view direction ], i.e.
+ * MultiHashEncoding(pts) and SphericalHarmonicsEncoding(viewdirs) of encoding/{multi_hash,spherical_harmonics}.py
+ * written side by side; pts_out [B n, 3] (or NULL) keeps the positions for nerf_hashgrid_backward.            */
+int nerf_ngp_encode(const float* rays, const float* z, int64_t B, int n, const float* tables, int L, int log2_T,
+                    int F, const int* resolutions_host, int sh_degree, float* x_out, float* pts_out, void* stream);
+
 /* ---------------------------------------------------------------- compositing (a13)
  * replaces: rendering/render.py:20-96 raw2outputs.  raw [B,n,4] = [rgb, sigma];
  * noise [B,n] (N(0,1), caller's RNG) may be NULL when raw_noise_std == 0.

@@ -16,6 +16,7 @@ from typing import Dict, Optional
 
 import torch
 
+from .. import _native as N
 from .. import parallel, sampling
 from ..encoding.multi_hash import MultiHashEncoding
 from ..encoding.spherical_harmonics import SphericalHarmonicsEncoding
@@ -50,7 +51,20 @@ class HashNeRF:
         self._pts = None
         self.timing = None                  # bench.py: list that receives (start, end) events around the table scatter
 
-    def features(self, rays: torch.Tensor, z: torch.Tensor):
+    def features(self, rays: torch.Tensor, z: torch.Tensor, need_pts: bool = True):
+        """x [B n, 48] = [MultiHashEncoding(o + z d) | SphericalHarmonicsEncoding(viewdirs)] in one call
+        (`nerf_ngp_encode`), and the sample positions for the table-gradient pass."""
+        B, n = z.shape
+        e = self.enc
+        x = torch.empty(B * n, 48, dtype=torch.float32, device=z.device)
+        pts = torch.empty(B * n, 3, dtype=torch.float32, device=z.device) if need_pts else None
+        N.check(N.lib().nerf_ngp_encode(N.ptr(N.f32(rays)), N.ptr(N.f32(z)), B, n, N.ptr(e.tables), e.n_levels,
+                                        e.log2_hashmap_size, e.n_features_per_level, e._res_c, 3, N.ptr(x), N.ptr(pts),
+                                        N.stream()))
+        return pts, x
+
+    def features_unfused(self, rays: torch.Tensor, z: torch.Tensor):
+        """The same rows from the stand-alone encoder classes (tests compare the two)."""
         B, n = z.shape
         pts = (rays[:, None, 0:3] + z[:, :, None] * rays[:, None, 3:6]).reshape(-1, 3)     # render.py:142
         feat = self.enc(pts)                                                               # [B n, 32]
@@ -59,7 +73,7 @@ class HashNeRF:
         return pts, x
 
     def query(self, rays: torch.Tensor, z: torch.Tensor, train: bool = False) -> torch.Tensor:
-        pts, x = self.features(rays, z)
+        pts, x = self.features(rays, z, need_pts=train)
         if train:
             self._pts = pts
         return self.mlp.forward(x, train=train).view(z.shape[0], z.shape[1], 4)

@@ -620,8 +620,13 @@ def test_ngp_field_gradients_and_training_track_oracle():
     assert torch.equal(tr.field.mlp.params.cpu(), orc.p.detach())
     rays, target = tr.sample_batch()
     ro, rd, tg = rays[:, 0:3].cpu(), rays[:, 3:6].cpu(), target.cpu()
-    # --- gradients of one batch (no update)
+    # --- fused row encoder == stand-alone encoders, bit for bit
     from nerf_meets_mlx_amd import sampling
+    z0 = sampling.sample_coarse(rays, 32)
+    pa, xa = tr.field.features(rays, z0)
+    pb, xb = tr.field.features_unfused(rays, z0)
+    assert torch.equal(pa, pb) and torch.equal(xa, xb)
+    # --- gradients of one batch (no update)
     from nerf_meets_mlx_amd.rendering import render
     from nerf_meets_mlx_amd.ops.metric import mse_loss_grad
     z = sampling.sample_coarse(rays, 32)
