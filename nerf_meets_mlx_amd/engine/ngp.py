@@ -97,14 +97,18 @@ class NGPTrainer(Trainer):
     ray, no importance pass).  Rays shard across ranks; MLP and table gradients are sum-all-reduced before Adam."""
 
     def __init__(self, images, poses, K, near: float = 2.0, far: float = 6.0, N_rand: int = 4096,
-                 n_depth_samples: int = 64, lrate: float = 1e-2, lrate_decay: int = 500, white_bkgd: bool = True,
+                 n_depth_samples: int = 64, lrate: float = 5e-4, lrate_decay: int = 500, white_bkgd: bool = True,
                  seed: int = 0, device="cuda", chunk: int = 1024 * 32, **hash_kw):
         super().__init__(images, poses, K, near=near, far=far, N_rand=N_rand, n_depth_samples=n_depth_samples,
                          N_importance=0, lrate=lrate, lrate_decay=lrate_decay, white_bkgd=white_bkgd, ref_quirks=True,
                          seed=seed, device=device, chunk=chunk)
         self.coarse = None                                   # the 8 x 256 network of the base class is not used
         self.field = HashNeRF(device=self.device, seed=seed, **hash_kw)
-        self.opt = Adam(lrate, betas=(0.9, 0.99), eps=1e-15, shared_state=False)
+        # Adam WITH bias correction: without it the first steps are lr * sign(g), which turns bf16 noise in near-zero
+        # table gradients into full-size steps and can drive sigma negative everywhere (a dead network under the
+        # reference's un-activated sigma, DESIGN.md section 7).  This loop is our wiring, so the choice is ours; lrate is
+        # the reference's 5e-4 (at 2e-3 both this trainer and the fp32 oracle collapse to sigma < 0 within 200 iterations).
+        self.opt = Adam(lrate, betas=(0.9, 0.99), eps=1e-8, bias_correction=True, shared_state=False)
 
     def train_step(self, rays=None, target=None, u=None) -> Dict[str, torch.Tensor]:
         if rays is None:

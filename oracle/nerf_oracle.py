@@ -626,17 +626,20 @@ class OracleImageFitter:
 class OracleNGP:
     """MultiHashEncoding(3,L,Nmin,Nmax,F,log2T) (encoding/multi_hash.py, intended semantics) for positions,
     SphericalHarmonicsEncoding(3,3) for view directions, NeRF(n_layers=2, width=64, in 32+16, view head)
-    (models/NeRF.py:160-243), render_rays' coarse pass (rendering/render.py:112-162) + raw2outputs + MSE, Adam without
-    bias correction on the MLP and on the tables.  Tables are initialised by the caller (same values as the device)."""
+    (models/NeRF.py:160-243), render_rays' coarse pass (rendering/render.py:112-162) + raw2outputs + MSE, Adam WITH bias
+    correction on the MLP and on the tables (this wiring is ours, not the reference's: without the correction the first
+    steps are lr * sign(g), which amplifies bf16 noise in near-zero table gradients and can push sigma below zero
+    everywhere -- a dead network under raw2outputs' un-activated sigma).  Tables are initialised by the caller (same values as the device)."""
 
-    def __init__(self, tables: torch.Tensor, resolutions, seed=0, n_samples=64, lrate=1e-2, lrate_decay=500,
-                 betas=(0.9, 0.99), eps=1e-15, emulate_bf16=False, near=2.0, far=6.0, white_bkgd=True):
+    def __init__(self, tables: torch.Tensor, resolutions, seed=0, n_samples=64, lrate=5e-4, lrate_decay=500,
+                 betas=(0.9, 0.99), eps=1e-8, bias_correction=True, emulate_bf16=False, near=2.0, far=6.0,
+                 white_bkgd=True):
         self.arch = NerfArch(channel_input=32, channel_input_views=16, n_layers=2, width=64, skips=(), use_viewdirs=True)
         self.p = flatten_params(self.arch, init_params(self.arch, seed)).requires_grad_(True)
         self.tables = tables.clone().float().requires_grad_(True)
         self.res = list(resolutions)
         self.n, self.lrate, self.decay, self.lr = n_samples, lrate, lrate_decay, lrate
-        self.betas, self.eps, self.emu = betas, eps, emulate_bf16
+        self.betas, self.eps, self.emu, self.bc = betas, eps, emulate_bf16, bias_correction
         self.near, self.far, self.white = near, far, white_bkgd
         self.mp = [torch.zeros_like(self.p), torch.zeros_like(self.p)]
         self.mt = [torch.zeros_like(self.tables), torch.zeros_like(self.tables)]
@@ -663,8 +666,8 @@ class OracleNGP:
     def step(self, rays_o, rays_d, target):
         loss, gp, gt = self.loss_and_grads(rays_o, rays_d, target)
         with torch.no_grad():
-            adam_step(self.p, gp, self.mp[0], self.mp[1], self.lr, self.betas[0], self.betas[1], self.eps)
-            adam_step(self.tables, gt, self.mt[0], self.mt[1], self.lr, self.betas[0], self.betas[1], self.eps)
+            adam_step(self.p, gp, self.mp[0], self.mp[1], self.lr, self.betas[0], self.betas[1], self.eps, self.bc, self.it + 1)
+            adam_step(self.tables, gt, self.mt[0], self.mt[1], self.lr, self.betas[0], self.betas[1], self.eps, self.bc, self.it + 1)
         self.it += 1
         self.lr = lr_schedule(self.lrate, self.decay, self.it)
         return float(loss)
