@@ -114,6 +114,9 @@ int nerf_hashgrid_backward(const float* x, int64_t M, const float* d_out, int L,
  * written side by side; pts_out [B n, 3] (or NULL) keeps the positions for nerf_hashgrid_backward.            */
 int nerf_ngp_encode(const float* rays, const float* z, int64_t B, int n, const float* tables, int L, int log2_T,
                     int F, const int* resolutions_host, int sh_degree, float* x_out, float* pts_out, void* stream);
+/* table gradient with the sample positions taken from rays / depths (o + z d) instead of a point list          */
+int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,
+                                int log2_T, int F, const int* resolutions_host, float* d_tables, void* stream);
 
 /* ---------------------------------------------------------------- compositing (a13)
  * replaces: rendering/render.py:20-96 raw2outputs.  raw [B,n,4] = [rgb, sigma];
@@ -198,6 +201,14 @@ int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void*
  * models sit behind fixed encodings and return NERF_E_UNSUPPORTED.                                             */
 int nerf_mlp_backward_inputs(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
                              int64_t M, void* dz, float* grads, float* d_x, void* stream);
+
+/* The same rows never leaving the chip: hash gathers + SH evaluated inside the 2 x 64 forward kernel (L = 16, F = 2,
+ * sh_degree = 3; arch = {2, 64, 32, 16, -1, 1}) -> raw [B,n,4]; acts as in nerf_query_fused.  The table gradient of
+ * such a query takes the sample positions from the rays again: nerf_hashgrid_backward_rays(d_out = the d_x of
+ * nerf_mlp_backward_inputs).                                                                                  */
+int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z, int64_t B,
+                         int n, const float* tables, int L, int log2_T, int F, const int* resolutions_host,
+                         int sh_degree, float* raw, void* acts, void* stream);
 
 /* ---------------------------------------------------------------- fused renderer (a14 / a18)
  * replaces: rendering/render.py:164-241 render_rays_eval (coarse pass, importance sampling, sort, second pass)

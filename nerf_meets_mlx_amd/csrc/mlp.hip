@@ -16,6 +16,7 @@
 // masks and the dW kernel consumes through LDS with ds_read_b64_tr_b16 (the sample axis
 // becomes the MFMA K axis there).
 #include "common.h"
+#include "hash_common.h"
 #include <string.h>
 
 #ifndef NERF_SPREAD_DMA
@@ -1670,21 +1671,56 @@ struct SmallArgs {
   float* d_x;            // [M,32] dL/d(position features) or nullptr
   void* acts; void* dz;
   int64_t astride, zstride;
+  // fused configs[4] query: rows are computed in the kernel from rays / depths / hash tables (16 levels x 2 features)
+  const float* rays; const float* z; int n; const float* tables; uint32_t T; ResTab rt;
 };
 
-template <bool STORE>
+// B fragments of one sample straight from the hash tables and the view direction: lane (r, h) owns channels
+// kperm(ks, h, j) of k-step ks = levels 8 ks + 4 (j >> 2) + 2 h + ((j & 3) >> 1), feature j & 1, i.e. the two lanes of
+// a sample split the 16 levels between them; SH degree 3 = 16 channels = one k-step.
+__device__ __forceinline__ void ngp_row_frags(const SmallArgs& a, int64_t m, int h, bf16x8 (&xin)[1][2], bf16x8 (&din)[1][1]) {
+  const float* rr = a.rays + (int64_t)((uint64_t)m / (unsigned)a.n) * NERF_RAY_STRIDE;
+  const float zv = a.z[m];
+  const float px = rr[0] + zv * rr[3], py = rr[1] + zv * rr[4], pz = rr[2] + zv * rr[5];      // render.py:142
+  const uint32_t mask = a.T - 1;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int l = 8 * ks + 4 * q + 2 * h + e;
+        const Corners c = corners_of(px, py, pz, a.rt.res[l], mask);
+        const FeatVec<2> fv = hash_level<2>(a.tables + (size_t)l * a.T * 2, c);
+        xin[0][ks][4 * q + 2 * e] = (__bf16)fv.v[0];
+        xin[0][ks][4 * q + 2 * e + 1] = (__bf16)fv.v[1];
+      }
+  float sh[16];
+  sh_eval(rr[8], rr[9], rr[10], 3, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) din[0][0][j] = (__bf16)(h == 0 ? sh[8 * (j >> 2) + (j & 3)] : sh[8 * (j >> 2) + 4 + (j & 3)]);
+}
+
+template <bool STORE, bool FUSED>
 __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
   constexpr int ST = 1;
   lds_load_stream(a.wf, a.bias);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int lane0 = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ntiles = (a.M + 31) >> 5;
   LdsW ws;
   for (int64_t tile0 = (int64_t)blockIdx.x * 8 + wv; tile0 < ntiles; tile0 += (int64_t)gridDim.x * 8) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));        // fragment addresses are per-tile values: the 31 LDS reads are not hoisted (spills)
+    const int r = lane & 31, h = lane >> 5;
     int64_t m = tile0 * 32 + r; if (m >= a.M) m = a.M - 1;
-    const float* row = a.x + m * LN::CIN;
     bf16x8 xin[ST][2], din[ST][1];
-    xin[0][0] = row_frag(row, 0, h, LN::CPOS); xin[0][1] = row_frag(row, 1, h, LN::CPOS);
-    din[0][0] = row_frag(row + LN::CPOS, 0, h, LN::CDIR);
+    if (FUSED) {
+      ngp_row_frags(a, m, h, xin, din);
+    } else {
+      const float* row = a.x + m * LN::CIN;
+      xin[0][0] = row_frag(row, 0, h, LN::CPOS); xin[0][1] = row_frag(row, 1, h, LN::CPOS);
+      din[0][0] = row_frag(row + LN::CPOS, 0, h, LN::CDIR);
+    }
 #define SINK(slot0) FragSink<STORE>{a.acts, tile0, a.astride, slot0, r, h}
 #define MASK_STORE(layer) do { if (STORE) *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0, a.astride, LN::A_MASK + (layer), r, h)) = mk[0]; } while (0)
     if (STORE) { store_frags<2>(a.acts, tile0, a.astride, LN::A_X, xin[0], r, h); store_frags<1>(a.acts, tile0, a.astride, LN::A_DX, din[0], r, h); }
@@ -1734,10 +1770,13 @@ __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
 __global__ void __launch_bounds__(512) mlp_small_bwd_kernel(SmallArgs a) {
   constexpr int ST = 1;
   lds_load_stream(a.wb, nullptr);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int lane0 = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ntiles = (a.M + 31) >> 5;
   LdsW ws;
   for (int64_t tile0 = (int64_t)blockIdx.x * 8 + wv; tile0 < ntiles; tile0 += (int64_t)gridDim.x * 8) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 31, h = lane >> 5;
     const int64_t m = tile0 * 32 + r;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (m < a.M && h == 0) g = *reinterpret_cast<const float4*>(a.d_raw + m * 4);
@@ -1955,6 +1994,7 @@ static void small_args(SmallArgs& a, const void* packed) {
   a.bias = reinterpret_cast<const float*>(base + (size_t)(LN::F_PADDED + LN::B_PADDED) * 1024);
   a.x = nullptr; a.d_raw = nullptr; a.out = nullptr; a.d_x = nullptr; a.acts = nullptr; a.dz = nullptr; a.M = 0;
   a.astride = small_astride16(); a.zstride = small_zstride16();
+  a.rays = nullptr; a.z = nullptr; a.n = 1; a.tables = nullptr; a.T = 0;
 }
 
 extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M,
@@ -1968,8 +2008,8 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     a.x = x; a.out = out; a.acts = acts; a.M = M;
     const int64_t nwg = ((M + 31) / 32 + 7) / 8;
     const dim3 g((unsigned)(nwg < 2048 ? nwg : 2048)), b(512);
-    if (acts) hipLaunchKernelGGL(mlp_small_fwd_kernel<true>, g, b, LN::LDS_BYTES, as_stream(stream), a);
-    else hipLaunchKernelGGL(mlp_small_fwd_kernel<false>, g, b, LN::LDS_BYTES, as_stream(stream), a);
+    if (acts) hipLaunchKernelGGL((mlp_small_fwd_kernel<true, false>), g, b, LN::LDS_BYTES, as_stream(stream), a);
+    else hipLaunchKernelGGL((mlp_small_fwd_kernel<false, false>), g, b, LN::LDS_BYTES, as_stream(stream), a);
     return check_launch("mlp forward (2x64 model)");
   }
   if (arch_kind(arch) == 1) {
@@ -2145,6 +2185,28 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   job(L::Z_D, 8, L::A_DPE, 2, L::P_WD, 283, 256, 128, 27, -1);                                     // dir0 | dirPE
   job(L::Z_RGB, 1, L::A_HD, 8, L::P_WR, 128, 0, 3, 128, L::P_BR);                                  // rgb
   return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astride16(), zstride16(), grads, s);
+}
+
+extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
+                                    int64_t B, int n, const float* tables, int L, int log2_T, int F,
+                                    const int* resolutions_host, int sh_degree, float* raw, void* acts, void* stream) {
+  NERF_REQUIRE(arch_kind(arch) == 2, NERF_E_UNSUPPORTED, "nerf_ngp_query_fused: needs the (2x64, in 32+16) model");
+  NERF_REQUIRE(L == 16 && F == 2 && sh_degree == 3, NERF_E_UNSUPPORTED,
+               "nerf_ngp_query_fused: fused rows exist for 16 levels x 2 features + SH degree 3 (use nerf_ngp_encode + nerf_mlp_forward otherwise)");
+  NERF_REQUIRE(log2_T >= 1 && log2_T <= 30, NERF_E_SHAPE, "nerf_ngp_query_fused: need 1<=log2_T<=30");
+  if (B <= 0 || n <= 0) return NERF_OK;
+  NERF_REQUIRE(packed && rays && z && tables && resolutions_host && raw, NERF_E_NULL, "nerf_ngp_query_fused: NULL pointer");
+  const int64_t M = B * n;
+  NERF_REQUIRE(M < (1ll << 31), NERF_E_SHAPE, "nerf_ngp_query_fused: B*n must be < 2^31");
+  SmallArgs a;
+  small_args(a, packed);
+  a.out = raw; a.acts = acts; a.M = M; a.rays = rays; a.z = z; a.n = n; a.tables = tables; a.T = 1u << log2_T;
+  for (int l = 0; l < 32; ++l) a.rt.res[l] = l < L ? (float)resolutions_host[l] : 0.0f;
+  const int64_t nwg = ((M + 31) / 32 + 7) / 8;
+  const dim3 g((unsigned)(nwg < 2048 ? nwg : 2048)), b(512);
+  if (acts) hipLaunchKernelGGL((mlp_small_fwd_kernel<true, true>), g, b, LN::LDS_BYTES, as_stream(stream), a);
+  else hipLaunchKernelGGL((mlp_small_fwd_kernel<false, true>), g, b, LN::LDS_BYTES, as_stream(stream), a);
+  return check_launch("nerf_ngp_query_fused");
 }
 
 extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,

@@ -12,6 +12,8 @@ nerf_composite_forward -> nerf_mse_loss_grad -> nerf_composite_backward -> nerf_
 dL/dfeatures) -> nerf_hashgrid_backward (float atomics) -> nerf_adam_step x 2.  torch only concatenates the two
 feature blocks and forms o + z d.
 """
+import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -48,7 +50,8 @@ class HashNeRF:
         self.mlp = NeRF(n_layers=2, width_layers=64, channel_input=32, channel_input_views=16,
                         list_skip_connection_layers=[], is_use_view_directions=True, device=device, seed=seed)
         self.table = _Flat(self.enc.tables, self.enc.grad)
-        self._pts = None
+        self._pts, self._rz = None, None
+        self.fused = os.environ.get("NERF_NGP_FUSED", "1") != "0"      # rows inside the forward kernel (default) or through HBM
         self.timing = None                  # bench.py: list that receives (start, end) events around the table scatter
 
     def features(self, rays: torch.Tensor, z: torch.Tensor, need_pts: bool = True):
@@ -72,24 +75,48 @@ class HashNeRF:
         x = torch.cat([feat.view(B, n, 32), shf[:, None, :].expand(B, n, 16)], dim=-1).reshape(B * n, 48)
         return pts, x
 
-    def query(self, rays: torch.Tensor, z: torch.Tensor, train: bool = False) -> torch.Tensor:
-        pts, x = self.features(rays, z, need_pts=train)
+    def query(self, rays: torch.Tensor, z: torch.Tensor, train: bool = False, fused: Optional[bool] = None) -> torch.Tensor:
+        """raw [B,n,4].  fused (default): hash gathers and SH are evaluated inside the 2 x 64 forward kernel
+        (`nerf_ngp_query_fused`), no [B n, 48] rows in HBM; fused=False goes through `features` + `mlp.forward`."""
+        B, n = z.shape
+        if fused is None:
+            fused = self.fused
+        if not fused:
+            pts, x = self.features(rays, z, need_pts=train)
+            self._pts, self._rz = (pts if train else None), None
+            return self.mlp.forward(x, train=train).view(B, n, 4)
+        e, m = self.enc, self.mlp
+        rays, z = N.f32(rays), N.f32(z)
+        raw = torch.empty(B, n, 4, dtype=torch.float32, device=z.device)
+        acts = None
         if train:
-            self._pts = pts
-        return self.mlp.forward(x, train=train).view(z.shape[0], z.shape[1], 4)
+            acts = m._workspace("acts", N.lib().nerf_mlp_acts_bytes(C.byref(m.arch), B * n))
+            m._acts_M = B * n
+            self._pts, self._rz = None, (rays, z)
+        N.check(N.lib().nerf_ngp_query_fused(C.byref(m.arch), N.ptr(m.packed()), N.ptr(rays), N.ptr(z), B, n,
+                                             N.ptr(e.tables), e.n_levels, e.log2_hashmap_size, e.n_features_per_level,
+                                             e._res_c, 3, N.ptr(raw), N.ptr(acts), N.stream()))
+        return raw
 
     def backward(self, d_raw: torch.Tensor):
         """(MLP gradient [13188], table gradient [L,T,F]) of the last query(train=True)."""
         grads, d_x = self.mlp.backward(d_raw, need_input_grad=True)
-        self.enc.grad.zero_()
+        e = self.enc
+        e.grad.zero_()
         if self.timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.enc.backward(self._pts, d_x)
+        if self._rz is not None:
+            rays, z = self._rz
+            N.check(N.lib().nerf_hashgrid_backward_rays(N.ptr(rays), N.ptr(z), z.shape[0], z.shape[1], N.ptr(d_x), e.n_levels,
+                                                        e.log2_hashmap_size, e.n_features_per_level, e._res_c,
+                                                        N.ptr(e.grad), N.stream()))
+        else:
+            e.backward(self._pts, d_x)
         if self.timing is not None:
             e1.record()
             self.timing.append((e0, e1))
-        return grads, self.enc.grad
+        return grads, e.grad
 
 
 class NGPTrainer(Trainer):

@@ -626,6 +626,15 @@ def test_ngp_field_gradients_and_training_track_oracle():
     pa, xa = tr.field.features(rays, z0)
     pb, xb = tr.field.features_unfused(rays, z0)
     assert torch.equal(pa, pb) and torch.equal(xa, xb)
+    # --- rows computed inside the forward kernel == rows through HBM (same bf16 fragments, same MFMAs), and the
+    # --- table gradient from rays == the table gradient from the point list
+    raw_f = tr.field.query(rays, z0, train=True, fused=True)
+    g0 = torch.randn_like(raw_f)
+    gm_f, gt_f = tr.field.backward(g0); gm_f, gt_f = gm_f.clone(), gt_f.clone()
+    raw_u = tr.field.query(rays, z0, train=True, fused=False)
+    gm_u, gt_u = tr.field.backward(g0)
+    assert torch.equal(raw_f, raw_u)
+    assert _rel_l2(gm_f.cpu(), gm_u.cpu()) < 1e-5 and _rel_l2(gt_f.cpu(), gt_u.cpu()) < 1e-5    # atomics: order only
     # --- gradients of one batch (no update)
     from nerf_meets_mlx_amd.rendering import render
     from nerf_meets_mlx_amd.ops.metric import mse_loss_grad

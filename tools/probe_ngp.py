@@ -38,3 +38,5 @@ print(f"  train: hash bwd {timeit(lambda: f.enc.backward(pts, d_x)):.3f} | grad 
 zr = sampling.sample_coarse(rr, 64)
 ptsr, xr = f.features(rr, zr)
 print(f"  render: features {timeit(lambda: f.features(rr, zr)):.3f} | hash fwd only {timeit(lambda: f.enc(ptsr)):.3f} | mlp fwd {timeit(lambda: f.mlp.forward(xr)):.3f}")
+print(f"  render: fused query {timeit(lambda: f.query(rr, zr)):.3f} | unfused query {timeit(lambda: f.query(rr, zr, fused=False)):.3f}")
+print(f"  train: fused query {timeit(lambda: f.query(rays, z, train=True)):.3f} | unfused {timeit(lambda: f.query(rays, z, train=True, fused=False)):.3f}")
