@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(512) read_k(const u32x4* __restrict__ src, int
 // two 16 KiB runs (dZ and activation fragments) fetched by LDS-DMA into a 4-stage ring, 3 tiles in flight, one
 // counted wait + barrier per tile, nothing computed.  tile_stride / second-run offset in 16-byte units.
 extern __shared__ __attribute__((aligned(16))) char smem[];
-template <int NT>
+template <int NT, int STAGES>
 __global__ void __launch_bounds__(512) dw_like(const u32x4* __restrict__ src, int ntiles, int64_t stride16, int64_t off2_16) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lo = (int)((int64_t)ntiles * blockIdx.x / gridDim.x), hi = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
@@ -57,14 +57,14 @@ __global__ void __launch_bounds__(512) dw_like(const u32x4* __restrict__ src, in
                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
     }
   };
-  for (int s = 0; s < 3; ++s) if (lo + s < hi) issue(lo + s, s);
+  for (int s = 0; s < STAGES - 1; ++s) if (lo + s < hi) issue(lo + s, s);
   for (int t = lo; t < hi; ++t) {
-    const int rem = hi - 1 - t;
+    const int rem = hi - 1 - t < STAGES - 2 ? hi - 1 - t : STAGES - 2;      // younger tiles in flight
     if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 3 < hi) issue(t + 3, (t - lo + 3) & 3);
+    if (t + STAGES - 1 < hi) issue(t + STAGES - 1, (t - lo + STAGES - 1) % STAGES);
   }
 }
 
@@ -89,8 +89,10 @@ int main() {
   time("store nt", [&](int g, int f) { hipLaunchKernelGGL(write_k<1>, dim3(g), dim3(512), 0, 0, buf, nfrag, f); });
   time("load", [&](int g, int f) { hipLaunchKernelGGL(read_k<0>, dim3(g), dim3(512), 0, 0, buf, nfrag, f, sink); });
   time("load nt", [&](int g, int f) { hipLaunchKernelGGL(read_k<1>, dim3(g), dim3(512), 0, 0, buf, nfrag, f, sink); });
-  hipFuncSetAttribute(reinterpret_cast<const void*>(dw_like<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 148480);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(dw_like<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 148480);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(dw_like<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 148480);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(dw_like<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 148480);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(dw_like<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 74752);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(dw_like<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 111616);
   struct Shape { const char* name; int64_t stride16, off2; };
   // contiguous 32 KiB tiles; the real layout (dZ block 154 KiB per tile, activation block in a second buffer ~2 GB away)
   const Shape shapes[] = {{"contiguous", 2048, 1024}, {"strided 160K + 2 GB", 10240, (2ll << 30) / 16}};
@@ -100,8 +102,8 @@ int main() {
     for (int nt = 0; nt < 2; ++nt)
       for (int grid : {256, 1024, 2560}) {
         auto launch = [&]() {
-          if (nt) hipLaunchKernelGGL(dw_like<1>, dim3(grid), dim3(512), 148480, 0, buf, ntiles, sh.stride16, sh.off2);
-          else hipLaunchKernelGGL(dw_like<0>, dim3(grid), dim3(512), 148480, 0, buf, ntiles, sh.stride16, sh.off2);
+          if (nt) hipLaunchKernelGGL((dw_like<1, 4>), dim3(grid), dim3(512), 148480, 0, buf, ntiles, sh.stride16, sh.off2);
+          else hipLaunchKernelGGL((dw_like<0, 4>), dim3(grid), dim3(512), 148480, 0, buf, ntiles, sh.stride16, sh.off2);
         };
         launch(); hipDeviceSynchronize();
         hipEventRecord(e0);
@@ -109,6 +111,24 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("dw-like %-20s %s grid %4d (%d tiles): %.2f TB/s\n", sh.name, nt ? "nt" : "  ", grid, ntiles, moved * 5.0 / (ms * 1e-3) / 1e12);
+      }
+  }
+  {   // two co-resident workgroups per CU with a 2-stage ring each (74 KiB), and one with 3 stages
+    const Shape sh = shapes[1];
+    const int ntiles = (int)((((2ll << 30)) / 16 - 2048) / sh.stride16);
+    const double moved = (double)ntiles * 32768;
+    for (int stages : {2, 3})
+      for (int grid : {512, 2560}) {
+        auto launch = [&]() {
+          if (stages == 2) hipLaunchKernelGGL((dw_like<1, 2>), dim3(grid), dim3(512), 74752, 0, buf, ntiles, sh.stride16, sh.off2);
+          else hipLaunchKernelGGL((dw_like<1, 3>), dim3(grid), dim3(512), 111616, 0, buf, ntiles, sh.stride16, sh.off2);
+        };
+        launch(); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("dw-like strided nt, %d stages (%s), grid %4d: %.2f TB/s\n", stages, stages == 2 ? "2 WGs/CU" : "1 WG/CU", grid, moved * 5.0 / (ms * 1e-3) / 1e12);
       }
   }
   return 0;
