@@ -833,3 +833,31 @@ def test_autograd_wrappers_match_explicit_backward():
     assert float(g_auto.abs().max()) > 0
     Adam(5e-4).update(m, g_auto)                                    # in-place update of the leaf works
     assert not torch.equal(m.params.detach().cpu(), flat)
+
+
+# ------------------------------------------------------------------------------ bench.py contract
+@pytest.mark.parametrize("extra", [[], ["--config", "ngp"], ["--n-importance", "0"]])
+def test_bench_prints_one_contract_json_line(extra):
+    """bench.py (small sizes, child process): exactly one JSON line with the driver's keys, a roofline object, finite
+    positive numbers; the cpu_baseline leg is exercised by the default run only (>= 10 s of CPU work)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--n-rand", "256",
+           "--render-rays", "2048", "--hw", "64", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "rays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and np.isfinite(d["value"]) and d["ms_per_step"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(d["value"] - (256 + 2048) * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
