@@ -77,8 +77,8 @@ constexpr int64_t PACKED_BYTES = F16_OFFSET + (int64_t)F16_PADDED * 1024;
 // activation store: fragment slots per 32-sample tile
 constexpr int A_PE = 0, A_DPE = 4, A_H0 = 6;       // H_l at A_H0 + 16 l, l = 0..7
 constexpr int A_FEAT = 134, A_HD = 150;
-// ReLU sign bits of H0..H7 and HD for the backward chain: one 16-byte word per lane and layer (bit 16 nt + i of
-// lane (r,h) = accumulator register i of n-tile nt), so the chain reads 9 KiB per tile instead of 150 KiB
+// ReLU sign bits of H0..H7 and HD for the backward chain: one 16-byte word per lane and layer (layout: see
+// finish_quarter), so the chain reads 9 KiB per tile instead of 150 KiB
 constexpr int A_MASK = 158, A_SLOTS = 167;
 // gradient store
 constexpr int Z_L0 = 0;                            // dZ_l at 16 l, l = 0..7
@@ -459,22 +459,54 @@ __device__ __forceinline__ void acc_init_bias(f32x16& acc, WS& ws, int slot_tile
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x2 pack2(float a, float b) {       // one v_cvt_pk_bf16_f32
+  const f32x2 v = {a, b};
+  return __builtin_convertvector(v, bf16x2);
+}
+__device__ __forceinline__ bf16x2 relu_pack(float a, float b) {
+  s16x2 q = __builtin_bit_cast(s16x2, pack2(a, b));
+  const s16x2 zero = {0, 0};
+  q = __builtin_elementwise_max(q, zero);
+  return __builtin_bit_cast(bf16x2, q);
+}
+// Packed 16-bit integer ops on bf16 bit patterns.  Inline asm on purpose: written as vector arithmetic, hipcc turns
+// them back into one float compare + select per element (and v_perm to re-pack), which is what they replace.
+// ReLU sign bits of a packed, already ReLU'd bf16 pair: 1 per non-zero half.
+__device__ __forceinline__ unsigned nonzero_bits(bf16x2 p) {
+  unsigned r;
+  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, p)));
+  return r;
+}
+// keep a half of the packed pair where bit B of the same half of `w` is set
+template <int B>
+__device__ __forceinline__ bf16x2 keep_where(bf16x2 p, unsigned w) {
+  unsigned sel, r;
+  asm("v_pk_lshrrev_b16 %0, %2, %1 op_sel_hi:[0,1]" : "=v"(sel) : "v"(w), "n"(B));      // both halves shift by the constant's low half
+  sel &= 0x00010001u;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, p)), "v"(sel));
+  return __builtin_bit_cast(bf16x2, r);
+}
+
 // Epilogue of one accumulator tile, in four quarters of 4 registers so that it can be spread between the MFMAs
 // of the NEXT n-tile (the two waves of a SIMD run the same stream in lockstep behind the ring barrier; an epilogue
 // done in one block would leave the matrix pipe idle in both at once).  ReLU is an integer max on the bit pattern:
 // one VALU op, without the canonicalising v_max hipcc puts in front of fmaxf on MFMA results.
+// Sign-bit words (MASKOUT): element e = 2 k + odd of n-tile nt -> bit 16 odd + 8 (nt & 1) + k of word nt >> 1, taken
+// from the packed ReLU'd pairs (non-zero half = active unit) instead of a compare + select per fp32 value.
 template <bool RELU, bool MASKOUT>
 __device__ __forceinline__ void finish_quarter(const f32x16& acc, int q, int nt, bf16x8& lo, bf16x8& hi, u32x4& mask) {
   unsigned w = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = 4 * q + e;
-    float v = acc[i];
-    if (MASKOUT) w |= (v > 0.0f) ? (1u << i) : 0u;
-    if (RELU) v = __int_as_float(max(__float_as_int(v), 0));   // ReLU on the bit pattern: one v_max_i32, no canonicalise
-    if (i < 8) lo[i] = (__bf16)v; else hi[i - 8] = (__bf16)v;
+  for (int p = 0; p < 2; ++p) {
+    const int i = 4 * q + 2 * p, k = 2 * q + p;
+    const bf16x2 pr = RELU ? relu_pack(acc[i], acc[i + 1]) : pack2(acc[i], acc[i + 1]);
+    if (MASKOUT) w |= nonzero_bits(pr) << k;
+    if (i < 8) { lo[i] = pr[0]; lo[i + 1] = pr[1]; } else { hi[i - 8] = pr[0]; hi[i - 7] = pr[1]; }
   }
-  if (MASKOUT) mask[nt >> 1] |= w << (16 * (nt & 1));      // bit 16 (nt&1) + i of word nt>>1
+  if (MASKOUT) mask[nt >> 1] |= w << (8 * (nt & 1));
 }
 
 __host__ __device__ constexpr int quarter_pos(int ks_count, int q) {   // k-step after which quarter q is retired
@@ -753,19 +785,6 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
 // B fragment, element j of lane group g = feature 16 (j>>2) + 4 g + (j&3) of the 32-feature k-step.
 // ==========================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16x2 pack2(float a, float b) {       // one v_cvt_pk_bf16_f32
-  const f32x2 v = {a, b};
-  return __builtin_convertvector(v, bf16x2);
-}
-__device__ __forceinline__ bf16x2 relu_pack(float a, float b) {
-  s16x2 q = __builtin_bit_cast(s16x2, pack2(a, b));
-  const s16x2 zero = {0, 0};
-  q = __builtin_elementwise_max(q, zero);
-  return __builtin_bit_cast(bf16x2, q);
-}
 namespace L16 {
 constexpr int F_L0 = 0, F_L1 = 32, F_L5 = 544, F_L6 = 704, F_L7 = 832, F_FA = 960, F_DIR = 1096, F_RGB = 1168;
 constexpr int CHUNKS = L::F16_PADDED / RING_CHUNK;     // 37
@@ -1043,15 +1062,30 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
 // backward chain: dZ_l for every layer (stored as fragment blocks for the dW kernel)
 // ------------------------------------------------------------------------------------------
 // backward epilogue quarter: ReLU' from the forward's sign bits, then bf16
+template <bool MASK, int Q, int ODD>
+__device__ __forceinline__ void finish_quarter_bwd_t(const f32x16& acc, bf16x8& lo, bf16x8& hi, unsigned w) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int i = 4 * Q + 2 * p;
+    bf16x2 pr = pack2(acc[i], acc[i + 1]);
+    if (MASK) pr = p == 0 ? keep_where<8 * ODD + 2 * Q>(pr, w) : keep_where<8 * ODD + 2 * Q + 1>(pr, w);
+    if (i < 8) { lo[i] = pr[0]; lo[i + 1] = pr[1]; } else { hi[i - 8] = pr[0]; hi[i - 7] = pr[1]; }
+  }
+}
 template <bool MASK>
 __device__ __forceinline__ void finish_quarter_bwd(const f32x16& acc, int q, int kt, bf16x8& lo, bf16x8& hi,
                                                    const u32x4& mask) {
-  const unsigned w = MASK ? (mask[kt >> 1] >> (16 * (kt & 1))) : 0xFFFFu;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = 4 * q + e;
-    const float v = (!MASK || ((w >> i) & 1u)) ? acc[i] : 0.0f;
-    if (i < 8) lo[i] = (__bf16)v; else hi[i - 8] = (__bf16)v;
+  const unsigned w = MASK ? mask[kt >> 1] : 0u;
+  // q and kt are compile-time constants at every call site (fully unrolled loops): the switch folds away
+  switch (2 * q + (kt & 1)) {
+    case 0: finish_quarter_bwd_t<MASK, 0, 0>(acc, lo, hi, w); break;
+    case 1: finish_quarter_bwd_t<MASK, 0, 1>(acc, lo, hi, w); break;
+    case 2: finish_quarter_bwd_t<MASK, 1, 0>(acc, lo, hi, w); break;
+    case 3: finish_quarter_bwd_t<MASK, 1, 1>(acc, lo, hi, w); break;
+    case 4: finish_quarter_bwd_t<MASK, 2, 0>(acc, lo, hi, w); break;
+    case 5: finish_quarter_bwd_t<MASK, 2, 1>(acc, lo, hi, w); break;
+    case 6: finish_quarter_bwd_t<MASK, 3, 0>(acc, lo, hi, w); break;
+    default: finish_quarter_bwd_t<MASK, 3, 1>(acc, lo, hi, w); break;
   }
 }
 
