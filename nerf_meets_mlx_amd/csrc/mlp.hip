@@ -15,6 +15,12 @@
 // 16 features, lane (r,h) at byte 32r+16h) which the backward chain kernel reloads as ReLU
 // masks and the dW kernel consumes through LDS with ds_read_b64_tr_b16 (the sample axis
 // becomes the MFMA K axis there).
+//
+// Map of the file: layouts + packing (namespace L) | weight sources (GlobalW: L1, RingW: LDS ring fed by LDS-DMA,
+// LdsW: LDS-resident) | layer_fwd / fwd_tiles and the 32x32x16 forward kernels | the 16x16x32 render forward
+// (mlp_fwd_ring16_kernel, the default for inference) | layer_bwd / bwd_tiles (dZ chain) | mlp_dw_kernel (dW / db) |
+// second layout: image-fitting model (namespace LI) | third layout: 2 x 64 model of configs[4] (namespace LN) |
+// C ABI entry points.
 #include "common.h"
 #include "hash_common.h"
 #include <string.h>
