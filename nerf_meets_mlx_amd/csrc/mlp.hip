@@ -2096,13 +2096,13 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
     total_units += units[j];
   }
   // Workgroups are dealt to CUs as they free up, so many short ones balance better than 256 long ones: about 80
-  // sample tiles per workgroup measured best (B=4096: n=64 -> ~1500 workgroups, n=192 -> ~3000+); the atomic flush
-  // (<= 256 KiB per workgroup) stays < 5 % of a workgroup's life at that size.
+  // sample tiles per workgroup measured best for n=64 (B=4096: ~1500 workgroups), ~170 for n=192 (2048 workgroups:
+  // 1.68 ms against 1.77 at 4096 and 3.06 at 256): 6-8 workgroups per CU over the launch, whatever their length.
   int target_wgs = g_dw_wgs;
   if (target_wgs <= 0) {
     target_wgs = (int)(ntiles * nj / 80);
     if (target_wgs < 256) target_wgs = 256;
-    if (target_wgs > 4096) target_wgs = 4096;
+    if (target_wgs > 2048) target_wgs = 2048;            // sweep (tools/sweep_dw.py): 1536-2048 is best at both batch sizes
   }
   int nw = 0;
   for (int j = 0; j < DW_MAX_JOBS; ++j) d.splits[j] = 0;

@@ -1,0 +1,28 @@
+import sys, torch
+sys.path.insert(0, ".")
+from nerf_meets_mlx_amd import _native
+from nerf_meets_mlx_amd.models.NeRF import NeRF
+dev = "cuda"
+def rays(B):
+    o = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1) * 4
+    d = -o / 4 + 0.2 * torch.randn(B, 3, device=dev)
+    r = torch.zeros(B, 11, device=dev); r[:, :3] = o; r[:, 3:6] = d; r[:, 6] = 2; r[:, 7] = 6
+    r[:, 8:] = d / d.norm(dim=-1, keepdim=True); return r
+def timeit(fn, it=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+opt = lambda k, v: _native.check(_native.lib().nerf_set_option(k, v))
+m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0)
+opt(b"bwd_stage", 2)
+for B, n in ((4096, 64), (4096, 192)):
+    r = rays(B); z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
+    g = torch.randn(B, n, 4, device=dev)
+    m.query(r, z, train=True); opt(b"bwd_stage", 0); m.backward(g); opt(b"bwd_stage", 2)
+    for rep in range(2):
+        for wgs in (0, 256, 512, 768, 1024, 1536, 2048, 3072, 4096):
+            opt(b"dw_workgroups", wgs)
+            print(f"n={n} dw_workgroups={wgs}: dW {timeit(lambda: m.backward(g)):.3f} ms", flush=True)
