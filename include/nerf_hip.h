@@ -238,7 +238,8 @@ int nerf_comm_destroy(void* comm);
  *                     4 LDS ring, 16x16x32 MFMA, 8 waves x 32 samples (render path only; auto picks it there) |
  *                     5 same with 4 waves x 64 samples.  Training kernels use 3 for every value >= 3.
  *   "ring_workgroups" persistent workgroups of the ring kernels (default 256 = one per CU)
- *   "dw_workgroups"   0 auto | workgroups of the weight-gradient kernel                       */
+ *   "dw_workgroups"   0 auto (256, one per CU) | workgroups of the weight-gradient kernel
+ *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)                       */
 int nerf_set_option(const char* key, int value);
 
 /* ---------------------------------------------------------------- optimiser (a21)

@@ -1862,6 +1862,7 @@ __global__ void __launch_bounds__(512) mlp_small_bwd_kernel(SmallArgs a) {
 }
 
 static int g_dw_wgs = 0;       // 0: automatic (see launch_dw)
+static int g_dw_bias = 128;    // per-tile fixed cost of a dW job in fragment units (cost model of the static split)
 static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW only (on whatever dz holds)
 static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
@@ -1903,6 +1904,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 256; return NERF_OK; }
   if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 0; return NERF_OK; }
+  if (!strcmp(key, "dw_unit_bias")) { g_dw_bias = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "bwd_stage")) { g_bwd_stage = value; return NERF_OK; }
   if (!strcmp(key, "dw_job_mask")) { g_dw_job_mask = value; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
@@ -2087,32 +2089,45 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
 // split the (dZ, H) jobs over workgroups and launch the dW kernel; grads[0..nparams) is overwritten
 static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
                      int64_t zstride, float* grads, hipStream_t s) {
-  // The dW pass is HBM-bound (every dZ / activation byte is read once per job, 128 FLOP/B), so a job's cost is
-  // its bytes per sample tile (nf + kf KiB).  One workgroup per CU (148 KiB LDS each): split the sample range of
-  // every job over ~256 workgroups in proportion to those bytes so that all of them finish together.
+  // A job's cost per sample tile = its bytes (nf + kf KiB) + a fixed part (barrier, waits, the 4 DMA issues per wave,
+  // transposed reads, MFMAs) worth about 128 KiB of streaming: single-job timings fit t = a (nf + kf + c0) with c0 = 24
+  // at a full grid, but under load the sweep over c0 keeps improving up to ~128 and is flat beyond (tools/sweep_dw.py).  Split the sample range of every job in proportion.
   int64_t units[DW_MAX_JOBS], total_units = 0;
   for (int j = 0; j < nj; ++j) {
-    units[j] = d.jobs[j].nf + d.jobs[j].kf;
+    units[j] = d.jobs[j].nf + d.jobs[j].kf + g_dw_bias;
     total_units += units[j];
   }
-  // Workgroups are dealt to CUs as they free up, so many short ones balance better than 256 long ones: about 80
-  // sample tiles per workgroup measured best for n=64 (B=4096: ~1500 workgroups), ~170 for n=192 (2048 workgroups:
-  // 1.68 ms against 1.77 at 4096 and 3.06 at 256): 6-8 workgroups per CU over the launch, whatever their length.
-  int target_wgs = g_dw_wgs;
-  if (target_wgs <= 0) {
-    target_wgs = (int)(ntiles * nj / 80);
-    if (target_wgs < 256) target_wgs = 256;
-    if (target_wgs > 2048) target_wgs = 2048;            // sweep (tools/sweep_dw.py): 1536-2048 is best at both batch sizes
-  }
+  // One workgroup per CU and launch (256), shares by largest remainder so that they sum to exactly 256: every
+  // workgroup starts at once and, with the cost model above, ends at about the same time -- one prologue and one atomic
+  // flush per CU instead of 6-16.  (tools/sweep_dw.py: 1.54 ms against 1.70 for the 192-sample pass, 0.52 against 0.66
+  // for the 64-sample pass; with the old byte-only cost model 256 workgroups took 3.1 ms because the small jobs'
+  // workgroups ran twice as long as the others.)  "dw_workgroups" overrides the total.
+  int target_wgs = g_dw_wgs > 0 ? g_dw_wgs : 256;
+  const int64_t max_splits = (ntiles + 3) / 4;                  // >= 4 sample tiles per workgroup
   int nw = 0;
+  double frac[DW_MAX_JOBS];
   for (int j = 0; j < DW_MAX_JOBS; ++j) d.splits[j] = 0;
   for (int j = 0; j < nj; ++j) {
-    int64_t splits = (units[j] * target_wgs + total_units / 2) / total_units;
-    const int64_t max_splits = (ntiles + 3) / 4;              // >= 4 sample tiles per workgroup
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    d.splits[j] = (int)splits;
-    nw += (int)splits;
+    const double share = (double)units[j] * target_wgs / (double)total_units;
+    int64_t sp = (int64_t)share;
+    frac[j] = share - (double)sp;
+    if (sp < 1) { sp = 1; frac[j] = 0.0; }
+    if (sp > max_splits) { sp = max_splits; frac[j] = 0.0; }
+    d.splits[j] = (int)sp;
+    nw += (int)sp;
+  }
+  while (nw < target_wgs) {                                     // hand out the remainder, largest fraction first
+    int best = -1;
+    for (int j = 0; j < nj; ++j)
+      if (d.splits[j] < max_splits && (best < 0 || frac[j] > frac[best])) best = j;
+    if (best < 0 || frac[best] <= 0.0) break;
+    d.splits[best] += 1; frac[best] = 0.0; nw += 1;
+  }
+  while (nw > target_wgs) {                                     // (minimum-of-one bumps) take back from the largest
+    int big = 0;
+    for (int j = 1; j < nj; ++j) if (d.splits[j] > d.splits[big]) big = j;
+    if (d.splits[big] <= 1) break;
+    d.splits[big] -= 1; nw -= 1;
   }
   hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * nparams, s);
   if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));

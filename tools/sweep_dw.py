@@ -22,7 +22,10 @@ for B, n in ((4096, 64), (4096, 192)):
     r = rays(B); z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
     g = torch.randn(B, n, 4, device=dev)
     m.query(r, z, train=True); opt(b"bwd_stage", 0); m.backward(g); opt(b"bwd_stage", 2)
-    for rep in range(2):
-        for wgs in (0, 256, 512, 768, 1024, 1536, 2048, 3072, 4096):
+    for bias in (64, 32, 128):
+        opt(b"dw_unit_bias", bias)
+        res = []
+        for wgs in (0, 256, 512, 768, 1024):
             opt(b"dw_workgroups", wgs)
-            print(f"n={n} dw_workgroups={wgs}: dW {timeit(lambda: m.backward(g)):.3f} ms", flush=True)
+            res.append(f"{wgs}:{timeit(lambda: m.backward(g)):.3f}")
+        print(f"n={n} bias={bias}: dW ms by workgroups  " + "  ".join(res), flush=True)
