@@ -237,8 +237,8 @@ int nerf_comm_destroy(void* comm);
  *   "mlp_variant"     0 auto | 1,2 weights via L1 (32 / 64 samples per wave) | 3 LDS ring, 32x32x16 MFMA |
  *                     4 LDS ring, 16x16x32 MFMA, 8 waves x 32 samples (render path only; auto picks it there) |
  *                     5 same with 4 waves x 64 samples.  Training kernels use 3 for every value >= 3.
- *   "ring_workgroups" persistent workgroups of the ring kernels (default 256 = one per CU)
- *   "dw_workgroups"   0 auto (256, one per CU) | workgroups of the weight-gradient kernel
+ *   "ring_workgroups" persistent workgroups of the ring kernels (0 = default: one per CU of the current device)
+ *   "dw_workgroups"   0 auto (one per CU) | workgroups of the weight-gradient kernel
  *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)                       */
 int nerf_set_option(const char* key, int value);
 

@@ -1870,7 +1870,19 @@ static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad
 static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad16; }
 static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: LDS ring, 8 waves x 32 samples, 32x32x16 MFMA,
                                 // 4: ring, 16x16x32 MFMA, 8 waves x 32 samples (inference only), 5: same, 4 waves x 64 samples
-static int g_ring_wgs = 256;     // persistent workgroups of the ring kernels (one per CU)
+static int g_ring_wgs = 0;       // persistent workgroups of the ring kernels; 0 = one per CU of the current device
+// CUs of the current device (256 on an MI355X in SPX mode), asked once: the persistent kernels and the dW split are
+// sized to it instead of to a constant
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+static inline int ring_wgs() { return g_ring_wgs > 0 ? g_ring_wgs : cu_count(); }
 
 template <class K>
 static void ensure_lds(K kernel, int bytes) {
@@ -1901,7 +1913,7 @@ using namespace nerf;
 extern "C" int nerf_set_option(const char* key, int value) {
   NERF_REQUIRE(key, NERF_E_NULL, "nerf_set_option: key is NULL");
   if (!strcmp(key, "mlp_variant")) { g_mlp_variant = value; return NERF_OK; }
-  if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 256; return NERF_OK; }
+  if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "dw_unit_bias")) { g_dw_bias = value >= 0 ? value : 0; return NERF_OK; }
@@ -1985,7 +1997,7 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   const int variant = (g_mlp_variant == 0) ? (MODE == 1 ? (acts ? 3 : 4) : 1) : g_mlp_variant;
   if ((variant == 4 || variant == 5) && MODE == 1 && !acts) {
     const int64_t nsuper = (M + 255) / 256;
-    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs));
+    const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs()));
     static bool once16 = false;
     if (!once16) {
       ensure_lds(mlp_fwd_ring16_kernel<8, 2>, RING16_LDS_BYTES); ensure_lds(mlp_fwd_ring16_kernel<4, 4>, RING16_LDS_BYTES);
@@ -1999,7 +2011,7 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   }
   if (variant >= 3 && MODE == 1) {
     const int64_t nsuper = (ntiles + 7) / 8;
-    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
+    const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), b(512);
     static bool once = false;
     if (!once) { ensure_lds(mlp_fwd_ring_kernel<1, true>, RING_LDS_BYTES); ensure_lds(mlp_fwd_ring_kernel<1, false>, RING_LDS_BYTES); once = true; }
     if (acts) hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, true>), g, b, RING_LDS_BYTES, s, a);
@@ -2061,7 +2073,7 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     const int64_t nsuper = ((M + 31) / 32 + 7) / 8;
     static bool once = false;
     if (!once) { ensure_lds(mlp_img_fwd_ring_kernel<true>, RING_LDS_BYTES); ensure_lds(mlp_img_fwd_ring_kernel<false>, RING_LDS_BYTES); once = true; }
-    const dim3 g((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), b(512);
+    const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), b(512);
     if (acts) hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<true>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     return check_launch("mlp forward (image model)");
@@ -2102,7 +2114,7 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   // flush per CU instead of 6-16.  (tools/sweep_dw.py: 1.54 ms against 1.70 for the 192-sample pass, 0.52 against 0.66
   // for the 64-sample pass; with the old byte-only cost model 256 workgroups took 3.1 ms because the small jobs'
   // workgroups ran twice as long as the others.)  "dw_workgroups" overrides the total.
-  int target_wgs = g_dw_wgs > 0 ? g_dw_wgs : 256;
+  int target_wgs = g_dw_wgs > 0 ? g_dw_wgs : cu_count();
   const int64_t max_splits = (ntiles + 3) / 4;                  // >= 4 sample tiles per workgroup
   int nw = 0;
   double frac[DW_MAX_JOBS];
@@ -2180,7 +2192,7 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     const int64_t nsuper = (ntiles + 7) / 8;
     static bool once_i = false;
     if (!once_i) { ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES); once_i = true; }
-    hipLaunchKernelGGL(mlp_img_bwd_ring_kernel, dim3((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), dim3(512),
+    hipLaunchKernelGGL(mlp_img_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
                        RING_LDS_BYTES, s, a);
     int rci = check_launch("mlp backward chain (image model)");
     if (rci) return rci;
@@ -2209,7 +2221,7 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     static bool once = false;
     if (!once) { ensure_lds(mlp_bwd_ring_kernel, RING_LDS_BYTES); once = true; }
     if (g_bwd_stage != 2)
-      hipLaunchKernelGGL(mlp_bwd_ring_kernel, dim3((unsigned)(nsuper < g_ring_wgs ? nsuper : g_ring_wgs)), dim3(512),
+      hipLaunchKernelGGL(mlp_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
                          RING_LDS_BYTES, s, b);
   } else {
     const int st = variant == 2 ? 2 : 1;
