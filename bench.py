@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 FLOP_PER_SAMPLE_FWD = 2 * 593408          # SURVEY 8d / BASELINE.md section 2
 BF16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA
+TRAIN_BYTES_PER_SAMPLE = (321 + 356 + 9) * 1024 / 32      # HBM bytes per sample of a training pass (8 TB/s peak)
 
 
 def main():
@@ -176,6 +177,9 @@ def main():
                    "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
         "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
         "train_mfma_frac": train_tf / BF16_MFMA_PEAK_TFLOPS, "render_mfma_frac": render_tf / BF16_MFMA_PEAK_TFLOPS,
+        # the training phase against its other roofline: bf16 activations + dZ written once (321 KiB per 32-sample tile)
+        # and read once by the weight-gradient jobs (356 KiB) + sign-bit words (9 KiB) = 21.4 KB per sample
+        "train_hbm_frac": TRAIN_BYTES_PER_SAMPLE * spr * args.n_rand / t_train / 8e12,
         "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
         "roofline": {"bound": "mfma", "kernel": ("mlp_fwd_ring16_kernel<8,2>" if args.mlp_variant in (0, 4) else f"fused MLP forward, mlp_variant {args.mlp_variant}") + " (render fine pass)", "achieved": achieved,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
