@@ -109,3 +109,19 @@ def test_blender_loader_roundtrip(tmp_path):
     assert (near, far) == (2.0, 6.0)
     half = load_blender_data(str(tmp_path), half_res=True, testskip=1)
     assert half[0].shape[1:3] == (4, 4) and abs(half[3][2] - f / 2) < 1e-9
+
+
+def test_bench_and_entry_scripts_parse_without_a_gpu():
+    """bench.py --help and importing __graft_entry__ must work on a CPU-only box (the driver's build check runs there)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--n-importance"):
+        assert flag in out.stdout
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; assert callable(g.build) and callable(g.smoke)"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-1000:]
+    for tool in ("summarize_rocprof.py", "psnr_parity.py", "psnr_parity_ngp.py", "bench_kernels.py"):
+        src = open(os.path.join(root, "tools", tool)).read()
+        compile(src, tool, "exec")
