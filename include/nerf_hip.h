@@ -111,12 +111,15 @@ int nerf_hashgrid_backward(const float* x, int64_t M, const float* d_out, int L,
 /* One input row per sample for the hash-grid model (BASELINE configs[4]; engine glue the reference never wrote):
  * x_out [B n, L F + (sh_degree+1)^2] = [ hash features of o + z d | SH of the ray's view direction ], i.e.
  * MultiHashEncoding(pts) and SphericalHarmonicsEncoding(viewdirs) of encoding/{multi_hash,spherical_harmonics}.py
- * written side by side; pts_out [B n, 3] (or NULL) keeps the positions for nerf_hashgrid_backward.            */
+ * written side by side; pts_out [B n, 3] (or NULL) keeps the positions for nerf_hashgrid_backward.  The grid sees
+ * (o + z d) * pos_scale + pos_offset: the affine map of the scene box onto [0,1]^3 (1, 0 = world coordinates).    */
 int nerf_ngp_encode(const float* rays, const float* z, int64_t B, int n, const float* tables, int L, int log2_T,
-                    int F, const int* resolutions_host, int sh_degree, float* x_out, float* pts_out, void* stream);
+                    int F, const int* resolutions_host, int sh_degree, float pos_scale, float pos_offset, float* x_out,
+                    float* pts_out, void* stream);
 /* table gradient with the sample positions taken from rays / depths (o + z d) instead of a point list          */
 int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,
-                                int log2_T, int F, const int* resolutions_host, float* d_tables, void* stream);
+                                int log2_T, int F, const int* resolutions_host, float pos_scale, float pos_offset,
+                                float* d_tables, void* stream);
 
 /* ---------------------------------------------------------------- compositing (a13)
  * replaces: rendering/render.py:20-96 raw2outputs.  raw [B,n,4] = [rgb, sigma];
@@ -208,7 +211,7 @@ int nerf_mlp_backward_inputs(const nerf_mlp_arch* arch, const void* packed, cons
  * nerf_mlp_backward_inputs).                                                                                  */
 int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z, int64_t B,
                          int n, const float* tables, int L, int log2_T, int F, const int* resolutions_host,
-                         int sh_degree, float* raw, void* acts, void* stream);
+                         int sh_degree, float pos_scale, float pos_offset, float* raw, void* acts, void* stream);
 
 /* ---------------------------------------------------------------- fused renderer (a14 / a18)
  * replaces: rendering/render.py:164-241 render_rays_eval (coarse pass, importance sampling, sort, second pass)

@@ -88,8 +88,9 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_kernel(PointSrc ps, int64_t 
 // sample position for the table-gradient pass
 __global__ void __launch_bounds__(256) ngp_dir_rows_kernel(const float* __restrict__ rays, const float* __restrict__ z,
                                                            int n, int64_t M, int deg, float* __restrict__ x_out,
-                                                           int64_t out_stride, int col0, float* __restrict__ pts_out) {
-  const PointSrc ps{nullptr, rays, z, n};
+                                                           int64_t out_stride, int col0, float* __restrict__ pts_out,
+                                                           float pos_scale, float pos_offset) {
+  const PointSrc ps{nullptr, rays, z, n, pos_scale, pos_offset};
   for (int64_t m = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
     const float* rr = rays + (int64_t)((uint64_t)m / (unsigned)n) * NERF_RAY_STRIDE;
     float o[25];
@@ -138,7 +139,8 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t 
 template <bool BWD>
 static int launch_hashgrid(const float* x, int64_t M, const float* tables, float* d_tables, const float* d_out, int L,
                            int log2_T, int F, const int* res, float* out, void* stream, const char* who,
-                           const float* rays = nullptr, const float* z = nullptr, int n = 1, int64_t out_stride = 0) {
+                           const float* rays = nullptr, const float* z = nullptr, int n = 1, int64_t out_stride = 0,
+                           float pos_scale = 1.0f, float pos_offset = 0.0f) {
   NERF_REQUIRE((x || (rays && z)) && res, NERF_E_NULL, "%s: NULL pointer", who);
   NERF_REQUIRE(L >= 1 && L <= 32 && log2_T >= 1 && log2_T <= 30, NERF_E_SHAPE, "%s: need 1<=L<=32, 1<=log2_T<=30", who);
   NERF_REQUIRE(F == 1 || F == 2 || F == 4 || F == 8, NERF_E_UNSUPPORTED, "%s: F must be 1, 2, 4 or 8", who);
@@ -149,8 +151,8 @@ static int launch_hashgrid(const float* x, int64_t M, const float* tables, float
   constexpr int LG = 4;                                   // levels per thread: LG x F contiguous floats per sample
   const dim3 g(grid_for(BWD ? M * F : M, 256), (unsigned)((L + LG - 1) / LG)), b(256);
   auto st = as_stream(stream);
-#define HG(FF) do { if (BWD) hipLaunchKernelGGL((hashgrid_bwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n}, M, d_tables, d_out, L, T, rt); \
-                    else hipLaunchKernelGGL((hashgrid_fwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n}, M, tables, L, T, rt, out, \
+#define HG(FF) do { if (BWD) hipLaunchKernelGGL((hashgrid_bwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, d_tables, d_out, L, T, rt); \
+                    else hipLaunchKernelGGL((hashgrid_fwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, tables, L, T, rt, out, \
                                             out_stride > 0 ? out_stride : (int64_t)L * FF); } while (0)
   switch (F) { case 1: HG(1); break; case 2: HG(2); break; case 4: HG(4); break; default: HG(8); }
 #undef HG
@@ -210,26 +212,26 @@ extern "C" int nerf_hashgrid_backward(const float* x, int64_t M, const float* d_
 }
 
 extern "C" int nerf_ngp_encode(const float* rays, const float* z, int64_t B, int n, const float* tables, int L,
-                               int log2_T, int F, const int* resolutions_host, int sh_degree, float* x_out,
-                               float* pts_out, void* stream) {
+                               int log2_T, int F, const int* resolutions_host, int sh_degree, float pos_scale,
+                               float pos_offset, float* x_out, float* pts_out, void* stream) {
   if (B <= 0 || n <= 0) return NERF_OK;
   NERF_REQUIRE(rays && z && tables && x_out, NERF_E_NULL, "nerf_ngp_encode: NULL pointer");
   NERF_REQUIRE(sh_degree >= 0 && sh_degree <= 4, NERF_E_SHAPE, "nerf_ngp_encode: sh_degree=%d must be in range [0, 4]", sh_degree);
   const int64_t M = B * n;
   const int64_t stride = (int64_t)L * F + (sh_degree + 1) * (sh_degree + 1);
   const int rc = launch_hashgrid<false>(nullptr, M, tables, nullptr, nullptr, L, log2_T, F, resolutions_host, x_out, stream,
-                                        "nerf_ngp_encode", rays, z, n, stride);
+                                        "nerf_ngp_encode", rays, z, n, stride, pos_scale, pos_offset);
   if (rc) return rc;
   hipLaunchKernelGGL(ngp_dir_rows_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), rays, z, n, M, sh_degree,
-                     x_out, stride, L * F, pts_out);
+                     x_out, stride, L * F, pts_out, pos_scale, pos_offset);
   return check_launch("nerf_ngp_encode");
 }
 
 extern "C" int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,
-                                           int log2_T, int F, const int* resolutions_host, float* d_tables,
-                                           void* stream) {
+                                           int log2_T, int F, const int* resolutions_host, float pos_scale,
+                                           float pos_offset, float* d_tables, void* stream) {
   if (B <= 0 || n <= 0) return NERF_OK;
   NERF_REQUIRE(rays && z && d_out && d_tables, NERF_E_NULL, "nerf_hashgrid_backward_rays: NULL pointer");
   return launch_hashgrid<true>(nullptr, B * n, nullptr, d_tables, d_out, L, log2_T, F, resolutions_host, nullptr, stream,
-                               "nerf_hashgrid_backward_rays", rays, z, n, 0);
+                               "nerf_hashgrid_backward_rays", rays, z, n, 0, pos_scale, pos_offset);
 }

@@ -78,18 +78,20 @@ __device__ __forceinline__ Corners corners_of(float px, float py, float pz, floa
 }
 
 // sample position: row m of x [M,3], or o + z d of ray m / n (rendering/render.py:142: one multiply, one add)
-struct PointSrc { const float* x; const float* rays; const float* z; int n; };
+struct PointSrc { const float* x; const float* rays; const float* z; int n; float scale, offset; };
 __device__ __forceinline__ void point_of(const PointSrc& ps, int64_t m, float& px, float& py, float& pz) {
   if (ps.rays) {
     const float* rr = ps.rays + (int64_t)((uint64_t)m / (unsigned)ps.n) * NERF_RAY_STRIDE;
     const float zv = ps.z[m];
-    px = rr[0] + zv * rr[3]; py = rr[1] + zv * rr[4]; pz = rr[2] + zv * rr[5];
+    // world position, then the affine map of the scene box onto the grid's unit cube (scale 1, offset 0 = none)
+    px = (rr[0] + zv * rr[3]) * ps.scale + ps.offset;
+    py = (rr[1] + zv * rr[4]) * ps.scale + ps.offset;
+    pz = (rr[2] + zv * rr[5]) * ps.scale + ps.offset;
   } else {
     px = ps.x[3 * m]; py = ps.x[3 * m + 1]; pz = ps.x[3 * m + 2];
   }
 }
 
-// the feature pair of one level at one point: 8 gathers + the reference's nested lerps, literally (multi_hash.py:122-131)
 template <int F>
 __device__ __forceinline__ FeatVec<F> hash_level(const float* __restrict__ tb, const Corners& c) {
   const FeatVec<F> e0 = load_entry<F>(tb, c.i[0]), e1 = load_entry<F>(tb, c.i[1]), e2 = load_entry<F>(tb, c.i[2]);

@@ -1712,7 +1712,7 @@ struct SmallArgs {
   void* acts; void* dz;
   int64_t astride, zstride;
   // fused configs[4] query: rows are computed in the kernel from rays / depths / hash tables (16 levels x 2 features)
-  const float* rays; const float* z; int n; const float* tables; uint32_t T; ResTab rt;
+  const float* rays; const float* z; int n; const float* tables; uint32_t T; ResTab rt; float pos_scale, pos_offset;
 };
 
 // B fragments of one sample straight from the hash tables and the view direction: lane (r, h) owns channels
@@ -1721,7 +1721,9 @@ struct SmallArgs {
 __device__ __forceinline__ void ngp_row_frags(const SmallArgs& a, int64_t m, int h, bf16x8 (&xin)[1][2], bf16x8 (&din)[1][1]) {
   const float* rr = a.rays + (int64_t)((uint64_t)m / (unsigned)a.n) * NERF_RAY_STRIDE;
   const float zv = a.z[m];
-  const float px = rr[0] + zv * rr[3], py = rr[1] + zv * rr[4], pz = rr[2] + zv * rr[5];      // render.py:142
+  // render.py:142, then the scene box -> unit cube map (same two roundings as hash_common.h:point_of)
+  const float px = (rr[0] + zv * rr[3]) * a.pos_scale + a.pos_offset, py = (rr[1] + zv * rr[4]) * a.pos_scale + a.pos_offset;
+  const float pz = (rr[2] + zv * rr[5]) * a.pos_scale + a.pos_offset;
   const uint32_t mask = a.T - 1;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
@@ -2048,7 +2050,7 @@ static void small_args(SmallArgs& a, const void* packed) {
   a.bias = reinterpret_cast<const float*>(base + (size_t)(LN::F_PADDED + LN::B_PADDED) * 1024);
   a.x = nullptr; a.d_raw = nullptr; a.out = nullptr; a.d_x = nullptr; a.acts = nullptr; a.dz = nullptr; a.M = 0;
   a.astride = small_astride16(); a.zstride = small_zstride16();
-  a.rays = nullptr; a.z = nullptr; a.n = 1; a.tables = nullptr; a.T = 0;
+  a.rays = nullptr; a.z = nullptr; a.n = 1; a.tables = nullptr; a.T = 0; a.pos_scale = 1.0f; a.pos_offset = 0.0f;
 }
 
 extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M,
@@ -2256,7 +2258,8 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
 
 extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
                                     int64_t B, int n, const float* tables, int L, int log2_T, int F,
-                                    const int* resolutions_host, int sh_degree, float* raw, void* acts, void* stream) {
+                                    const int* resolutions_host, int sh_degree, float pos_scale, float pos_offset,
+                                    float* raw, void* acts, void* stream) {
   NERF_REQUIRE(arch_kind(arch) == 2, NERF_E_UNSUPPORTED, "nerf_ngp_query_fused: needs the (2x64, in 32+16) model");
   NERF_REQUIRE(L == 16 && F == 2 && sh_degree == 3, NERF_E_UNSUPPORTED,
                "nerf_ngp_query_fused: fused rows exist for 16 levels x 2 features + SH degree 3 (use nerf_ngp_encode + nerf_mlp_forward otherwise)");
@@ -2268,6 +2271,7 @@ extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packe
   SmallArgs a;
   small_args(a, packed);
   a.out = raw; a.acts = acts; a.M = M; a.rays = rays; a.z = z; a.n = n; a.tables = tables; a.T = 1u << log2_T;
+  a.pos_scale = pos_scale; a.pos_offset = pos_offset;
   for (int l = 0; l < 32; ++l) a.rt.res[l] = l < L ? (float)resolutions_host[l] : 0.0f;
   const int64_t nwg = ((M + 31) / 32 + 7) / 8;
   const dim3 g((unsigned)(nwg < 2048 ? nwg : 2048)), b(512);

@@ -633,7 +633,7 @@ class OracleNGP:
 
     def __init__(self, tables: torch.Tensor, resolutions, seed=0, n_samples=64, lrate=5e-4, lrate_decay=500,
                  betas=(0.9, 0.99), eps=1e-8, bias_correction=True, emulate_bf16=False, near=2.0, far=6.0,
-                 white_bkgd=True):
+                 white_bkgd=True, bound=1.5):
         self.arch = NerfArch(channel_input=32, channel_input_views=16, n_layers=2, width=64, skips=(), use_viewdirs=True)
         self.p = flatten_params(self.arch, init_params(self.arch, seed)).requires_grad_(True)
         self.tables = tables.clone().float().requires_grad_(True)
@@ -641,6 +641,7 @@ class OracleNGP:
         self.n, self.lrate, self.decay, self.lr = n_samples, lrate, lrate_decay, lrate
         self.betas, self.eps, self.emu, self.bc = betas, eps, emulate_bf16, bias_correction
         self.near, self.far, self.white = near, far, white_bkgd
+        self.pos_scale, self.pos_offset = (1.0, 0.0) if bound is None else (1.0 / (2.0 * bound), 0.5)   # scene box -> unit cube
         self.mp = [torch.zeros_like(self.p), torch.zeros_like(self.p)]
         self.mt = [torch.zeros_like(self.tables), torch.zeros_like(self.tables)]
         self.it = 0
@@ -650,7 +651,7 @@ class OracleNGP:
         z = sample_z_uniform(near, far, self.n)
         pts = o[..., None, :] + d[..., None, :] * z[..., :, None]
         B, n = z.shape
-        feat = hashgrid_encoding(pts.reshape(-1, 3), self.tables, self.res).reshape(B, n, -1)
+        feat = hashgrid_encoding(pts.reshape(-1, 3) * self.pos_scale + self.pos_offset, self.tables, self.res).reshape(B, n, -1)
         shf = sh_encoding(viewdirs, 3)
         x = torch.cat([feat, shf[:, None, :].expand(B, n, shf.shape[-1])], -1).reshape(B * n, -1)
         raw = nerf_forward(self.arch, unflatten_params(self.arch, self.p), x, self.emu).reshape(B, n, 4)
