@@ -20,6 +20,18 @@ __global__ void __launch_bounds__(512) write_k(u32x4* __restrict__ dst, int64_t 
       if (NT) __builtin_nontemporal_store(v, p); else *p = v;
     }
 }
+// the fragment stores of the training kernels: lane (r = l & 31, h = l >> 5) writes 16 B at byte 32 r + 16 h
+template <int NT>
+__global__ void __launch_bounds__(512) write_frag_k(u32x4* __restrict__ dst, int64_t nfrag, int frags_per_wave) {
+  const int lane = threadIdx.x & 63, pos = 2 * (lane & 31) + (lane >> 5);
+  const int64_t wave = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 8;
+  u32x4 v = {(unsigned)lane, 1u, 2u, 3u};
+  for (int64_t f0 = wave * frags_per_wave; f0 < nfrag; f0 += nwaves * frags_per_wave)
+    for (int i = 0; i < frags_per_wave && f0 + i < nfrag; ++i) {
+      u32x4* p = dst + (f0 + i) * 64 + pos;
+      if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+    }
+}
 template <int NT>
 __global__ void __launch_bounds__(512) read_k(const u32x4* __restrict__ src, int64_t nfrag, int frags_per_wave, unsigned* sink) {
   const int lane = threadIdx.x & 63;
@@ -82,11 +94,13 @@ int main() {
         for (int r = 0; r < 5; ++r) launch(grid, fpw);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("%-12s grid %4d frags/wave %2d : %.2f TB/s\n", name, grid, fpw, bytes * 5.0 / (ms * 1e-3) / 1e12);
+        printf("%-14s grid %4d frags/wave %2d : %.2f TB/s\n", name, grid, fpw, bytes * 5.0 / (ms * 1e-3) / 1e12);
       }
   };
   time("store", [&](int g, int f) { hipLaunchKernelGGL(write_k<0>, dim3(g), dim3(512), 0, 0, buf, nfrag, f); });
   time("store nt", [&](int g, int f) { hipLaunchKernelGGL(write_k<1>, dim3(g), dim3(512), 0, 0, buf, nfrag, f); });
+  time("store frag", [&](int g, int f) { hipLaunchKernelGGL(write_frag_k<0>, dim3(g), dim3(512), 0, 0, buf, nfrag, f); });
+  time("store frag nt", [&](int g, int f) { hipLaunchKernelGGL(write_frag_k<1>, dim3(g), dim3(512), 0, 0, buf, nfrag, f); });
   time("load", [&](int g, int f) { hipLaunchKernelGGL(read_k<0>, dim3(g), dim3(512), 0, 0, buf, nfrag, f, sink); });
   time("load nt", [&](int g, int f) { hipLaunchKernelGGL(read_k<1>, dim3(g), dim3(512), 0, 0, buf, nfrag, f, sink); });
   hipFuncSetAttribute(reinterpret_cast<const void*>(dw_like<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 148480);
