@@ -1273,7 +1273,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_frag, int u, int hq, i
   return cvt.v;
 }
 
-__global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
+#ifndef NERF_DW_WAVES
+#define NERF_DW_WAVES 16
+#endif
+constexpr int DW_WAVES = NERF_DW_WAVES;          // 8: 4 x 2 output tiles per wave; 16: 2 x 2 (half the accumulators, 4 waves per SIMD)
+constexpr int DW_NPW = 32 / DW_WAVES;            // n-tiles per wave = DMAs per wave per tile
+__global__ void __launch_bounds__(64 * DW_WAVES) mlp_dw_kernel(DwArgs a) {
   char* smem = ring_smem;                             // the one dynamic-LDS array of this file
   int bj = blockIdx.x, job_id = 0;
   while (bj >= a.splits[job_id]) { bj -= a.splits[job_id]; ++job_id; }
@@ -1282,20 +1287,22 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
   const int tile_hi = (int)((int64_t)a.ntiles * (bj + 1) / a.splits[job_id]);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wv >> 2, wc = wv & 3;
+  const int wr = wv >> 2, wc = wv & 3;                  // wave rows: DW_WAVES / 4
   const int n_tiles = (jb.nf + 1) >> 1, k_tiles = (jb.kf + 1) >> 1;
   const int nf_pad = n_tiles * 2;
   const int nfk = jb.nf + jb.kf;                        // real fragments per sample tile (<= 32)
-  // this wave's output tiles: n-tiles wr*4 + (0..3), k-tiles wc*2 + (0..1)
-  const bool active = (wr * 4 < n_tiles) && (wc * 2 < k_tiles);
-  f32x16 acc[4][2];
+  // this wave's output tiles: n-tiles wr*DW_NPW + (0..DW_NPW-1), k-tiles wc*2 + (0..1)
+  const bool active = (wr * DW_NPW < n_tiles) && (wc * 2 < k_tiles);
+  f32x16 acc[DW_NPW][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < DW_NPW; ++i)
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][k][e] = 0.0f;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[DW_NPW];
+#pragma unroll
+  for (int i = 0; i < DW_NPW; ++i) bsum[i] = 0.0f;
   const int g16 = lane >> 4, i16 = lane & 15, hq = g16 >> 1, fsel = g16 & 1;
   const bf16x8* dzp = reinterpret_cast<const bf16x8*>(a.dz) + lane;
   const bf16x8* acp = reinterpret_cast<const bf16x8*>(a.acts) + lane;
@@ -1304,19 +1311,19 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
 
   // odd fragment counts (rgb / alpha jobs: nf = 1): the partner fragment of the tile is never written by DMA
   if (jb.nf & 1) {
-    for (int c = tid; c < DW_STAGES * 64; c += 512) {
+    for (int c = tid; c < DW_STAGES * 64; c += 64 * DW_WAVES) {
       bf16x8 zv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) zv[j] = (__bf16)0.0f;
       *reinterpret_cast<bf16x8*>(smem + (c >> 6) * DW_STAGE_BYTES + jb.nf * DW_FRAG_STRIDE + (c & 63) * 16) = zv;
     }
   }
-  // every wave issues exactly 4 DMAs per tile so that vmcnt arithmetic is uniform: fragment ids wv, wv+8, wv+16, wv+24
+  // every wave issues exactly DW_NPW DMAs per tile so that vmcnt arithmetic is uniform: fragment ids wv + DW_WAVES k
   auto issue = [&](int tile, int stage) {
     const unsigned st = lds0 + __builtin_amdgcn_readfirstlane(stage) * DW_STAGE_BYTES;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = wv + 8 * k;
+    for (int k = 0; k < DW_NPW; ++k) {
+      const int i = wv + DW_WAVES * k;
       if (i < jb.nf) dma_frag_nt(dzp + (int64_t)tile * a.zstride + (jb.dz_slot + i) * 64, st + i * DW_FRAG_STRIDE);
       else if (i < nfk) dma_frag_nt(acp + (int64_t)tile * a.astride + (jb.act_slot + (i - jb.nf)) * 64,
                                  st + (nf_pad + i - jb.nf) * DW_FRAG_STRIDE);
@@ -1332,9 +1339,15 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
     const int rem = tile_hi - 1 - tile;                 // tiles issued after this one and still in flight (<= 2)
     // lgkmcnt(0): this wave's transposed reads of the previous tile are complete before the barrier lets another
     // wave's DMA refill that stage (hipcc may sink register-only MFMAs, and their waits, below an asm statement)
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (DW_NPW == 4) {
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                       // tile landed for every wave; stage (tile-1)%4 is free
     if (tile + DW_STAGES - 1 < tile_hi) issue(tile + DW_STAGES - 1, (tile - tile_lo + DW_STAGES - 1) % DW_STAGES);
     const char* st = smem + ((tile - tile_lo) % DW_STAGES) * DW_STAGE_BYTES;
@@ -1353,8 +1366,8 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
           bfr[k] = tr_frag(st + f * DW_FRAG_STRIDE, u, hq, i16);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int nt = wr * 4 + i;
+        for (int i = 0; i < DW_NPW; ++i) {
+          const int nt = wr * DW_NPW + i;
           const int f = (nt < n_tiles ? 2 * nt : 0) + fsel;
           const bf16x8 afr = tr_frag(st + f * DW_FRAG_STRIDE, u, hq, i16);
 #if NERF_ABLATE != 5          // timing-only build 5: no bias row sums
@@ -1380,8 +1393,8 @@ __global__ void __launch_bounds__(512, 2) mlp_dw_kernel(DwArgs a) {
 #endif
   const int rr = lane & 31, hh = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int nt = wr * 4 + i;
+  for (int i = 0; i < DW_NPW; ++i) {
+    const int nt = wr * DW_NPW + i;
     if (nt >= n_tiles) continue;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -2152,7 +2165,7 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
     lds_attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(512), DW_LDS_BYTES, s, d);
+  hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
   return check_launch("mlp dW");
 }
 
