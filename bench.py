@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--config", choices=["nerf", "ngp"], default="nerf",
                     help="nerf: 8x256 NeRF, the headline workload (BASELINE configs[1-3]); ngp: hash grid + 2x64 MLP (configs[4])")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under a launcher: start one rank per GPU ourselves (torch.distributed.run, RCCL rendezvous on 127.0.0.1)
+        # BEFORE anything in this process touches the GPU, and leave with the children's exit code.
+        sys.exit(spawn_ranks(args.gpus))
 
     from nerf_meets_mlx_amd import _native, parallel
     from nerf_meets_mlx_amd.dataset import synthetic
@@ -55,7 +59,9 @@ def main():
     from nerf_meets_mlx_amd.rendering import ray
 
     rank, world, local = parallel.init_from_env(os.environ.get("NERF_DIST_BACKEND"))   # default: nccl (= RCCL) on GPUs
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _native.check(_native.lib().nerf_set_option(b"mlp_variant", args.mlp_variant))
@@ -146,26 +152,26 @@ def main():
     train_tf = 3 * FLOP_PER_SAMPLE_FWD * spr * args.n_rand / t_train / 1e12
     render_tf = FLOP_PER_SAMPLE_FWD * spr * args.render_rays / t_render / 1e12
     achieved = flop / (k_ms * 1e-3) / 1e12
-    # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of
-    # this same command, committed under profiles/); null when no measurement matches the workload
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fp:
-            pm = json.load(fp)
-        if pm.get("samples_per_launch") == args.render_rays * n_fine:
-            traffic = pm["hbm_bytes_per_launch"]
-    except OSError:
-        pass
-    # matrix-pipe busy cycles / all SIMD cycles of that kernel (PMC passes committed under profiles/), null if absent
-    busy = None
-    try:
-        import csv
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_lds.csv")) as fp:
-            for r in csv.DictReader(fp):
-                if "mlp_fwd_ring16_kernel<8, 2>" in r["kernel"] and args.mlp_variant in (0, 4) and traffic is not None:
-                    busy = float(r["mfma_busy_frac_of_cycles"])
-    except OSError:
-        pass
+    # HBM bytes per launch of that kernel: NOT measured by this run -- taken from the newest committed PMC passes of this
+    # same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh) when their
+    # samples-per-launch matches this workload; labelled as cached in the line.  null otherwise.
+    traffic, traffic_src = None, None
+    tpath = _latest_profile("r0*_pmc_traffic.json")
+    if tpath:
+        try:
+            with open(tpath) as fp:
+                pm = json.load(fp)
+            if pm.get("samples_per_launch") == args.render_rays * n_fine:
+                traffic = pm["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{os.path.basename(tpath)} (cached PMC run of this command, not this run; " + pm.get("note", "FETCH_SIZE + WRITE_SIZE") + ")"
+        except (OSError, ValueError, KeyError):
+            pass
+    # matrix-pipe busy cycles / all SIMD cycles of that kernel (same caveat: cached PMC pass), null if absent
+    busy, busy_src = None, None
+    bpath = _latest_profile("r0*_pmc_mfma_lds.csv")
+    if bpath and args.mlp_variant in (0, 4) and NI == 128 and args.render_rays == 32768:
+        busy = _read_pmc_busy(bpath, "mlp_fwd_ring16_kernel<8,2>")
+        busy_src = f"profiles/{os.path.basename(bpath)} (cached PMC run)" if busy is not None else None
     line = {
         "metric": f"train+render rays/sec on Lego {H}x{W} (synthetic), " + (f"coarse+fine 64+{NI}" if NI > 0 else "coarse-only 64"),
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,7 +189,8 @@ def main():
         "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
         "roofline": {"bound": "mfma", "kernel": ("mlp_fwd_ring16_kernel<8,2>" if args.mlp_variant in (0, 4) else f"fused MLP forward, mlp_variant {args.mlp_variant}") + " (render fine pass)", "achieved": achieved,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "mfma_busy_cycles_frac": busy, "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "traffic_source": traffic_src,
+                     "mfma_busy_cycles_frac": busy, "mfma_busy_source": busy_src, "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
                      "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * n_fine},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -192,6 +199,54 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with N
+    ranks (child processes; the parent never initialises the GPU, and nothing is exec'ed after GPU init)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _read_pmc_busy(path, kernel_substr):
+    """mfma_busy_frac_of_cycles of the first row whose kernel name contains kernel_substr.  Kernel names contain commas
+    (template arguments); rows are parsed from the right so that both quoted and unquoted files read correctly."""
+    try:
+        with open(path) as fp:
+            lines = [ln.rstrip("\n") for ln in fp if ln.strip()]
+    except OSError:
+        return None
+    import csv
+    header = next(csv.reader([lines[0]]))
+    k = len(header)
+    col = header.index("mfma_busy_frac_of_cycles") if "mfma_busy_frac_of_cycles" in header else None
+    if col is None:
+        return None
+    for ln in lines[1:]:
+        row = next(csv.reader([ln]))
+        if len(row) != k:                                     # unquoted name with commas: split the numeric tail off
+            tail = ln.rsplit(",", k - 1)
+            row = [tail[0].strip('"')] + tail[1:]
+        if kernel_substr.replace(" ", "") in row[0].replace(" ", ""):
+            try:
+                return float(row[col])
+            except ValueError:
+                return None
+    return None
+
+
+def _latest_profile(pattern):
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return c[-1] if c else None
 
 
 def bench_ngp(args, imgs, poses, rposes, K, rank, world, dev):
@@ -254,48 +309,107 @@ def bench_ngp(args, imgs, poses, rposes, K, rank, world, dev):
                      "ms_per_launch": k_ms, "samples_per_launch": M,
                      "note": "atomic-rate bound: 256 float atomics per sample at ~20 G/s (device-scope atomics execute memory-side)"},
     }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_ngp(args)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(args):
-    """The CPU oracle (op-for-op torch-CPU restatement of the reference path) on a bounded sample
-    of the same workload: same train:render ray ratio, small batch, all host cores."""
-    from oracle import nerf_oracle as O
-    # host share of a 1-GPU box: the scheduler affinity when it is set, never more than 16 threads
-    # (an 8-GPU host exposes 256 logical CPUs to every process; oversubscribing them makes torch-CPU crawl)
+def _host_cores():
+    """Host share of a 1-GPU box: the scheduler affinity when it is set, never more than 16 threads (an 8-GPU host
+    exposes 256 logical CPUs to every process; oversubscribing them makes torch-CPU crawl)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
-    torch.set_num_threads(cores)
-    arch = O.NerfArch()
-    tr = O.OracleTrainer(arch, 64, 128, seed=0)
-    b_train, b_render, steps = 256, 2048, 3
-    g = torch.Generator().manual_seed(0)
-    o = torch.nn.functional.normalize(torch.randn(b_render, 3, generator=g), dim=-1) * 4.0
-    d = -o / 4.0 + 0.2 * torch.randn(b_render, 3, generator=g)
-    y = torch.rand(b_train, 3, generator=g)
-    pc, pf = (O.unflatten_params(arch, tr.pc.detach()), O.unflatten_params(arch, tr.pf.detach()))
+    return max(1, min(cores, 16))
 
-    def one():
-        tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, 128, generator=g))
-        with torch.no_grad():
-            O.render_rays_eval(arch, pc, pf, O.pack_rays(o, d, 2.0, 6.0), 64, 128, torch.rand(b_render, 128, generator=g), True)
-    one()
+
+def cpu_baseline(args):
+    """The CPU oracle (op-for-op torch-CPU fp32 restatement of the reference path, `kind: port`) at the size SURVEY
+    8(d) specifies: training at B = 1024 rays (lego.txt N_rand), 1 warm-up + up to 20 timed steps, and a render slice
+    of 65 536 rays in 4096-ray chunks (coarse 64 + fine 64+128 like the GPU step; coarse-only when --n-importance 0).
+    Each leg is time-boxed (about 60 s) so that a slow host still finishes: the steps / rays actually timed are in
+    `sample`.  `value` combines the two legs in the GPU step's train : render ray mix."""
+    from oracle import nerf_oracle as O
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    NI = args.n_importance
+    arch = O.NerfArch()
+    tr = O.OracleTrainer(arch, 64, NI, seed=4)
+    b_train, n_render, chunk = 1024, 65536, 4096
+    g = torch.Generator().manual_seed(0)
+    o = torch.nn.functional.normalize(torch.randn(n_render, 3, generator=g), dim=-1) * 4.0
+    d = -o / 4.0 + 0.2 * torch.randn(n_render, 3, generator=g)
+    y = torch.rand(b_train, 3, generator=g)
+    un = max(NI, 1)
+    tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))          # warm-up
     t0 = time.perf_counter()
+    steps = 0
+    while steps < 20 and (steps < 3 or time.perf_counter() - t0 < 60.0):
+        tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))
+        steps += 1
+    t_train = time.perf_counter() - t0
+    pc = O.unflatten_params(arch, tr.pc.detach())
+    pf = O.unflatten_params(arch, tr.pf.detach()) if tr.pf is not None else None
+    t1 = time.perf_counter()
     done = 0
-    while done < steps or (time.perf_counter() - t0 < 10.0 and done < 4 * steps):     # 10-30 s of CPU work
-        one()
-        done += 1
-    steps = done
-    dt = time.perf_counter() - t0
-    return {"value": (b_train + b_render) * steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} steps of (train {b_train} rays + render {b_render} rays), coarse+fine 64+128, torch-CPU fp32 oracle",
-            "seconds": dt}
+    with torch.no_grad():
+        while done < n_render and (done < 2 * chunk or time.perf_counter() - t1 < 60.0):
+            rays = O.pack_rays(o[done:done + chunk], d[done:done + chunk], 2.0, 6.0)
+            if NI > 0:
+                O.render_rays_eval(arch, pc, pf, rays, 64, NI, torch.rand(rays.shape[0], NI, generator=g), True)
+            else:
+                O.render_rays(arch, pc, rays, 64, True)
+            done += rays.shape[0]
+    t_render = time.perf_counter() - t1
+    train_rps, render_rps = b_train * steps / t_train, done / t_render
+    mix_t = args.n_rand / train_rps + args.render_rays / render_rps               # CPU seconds for one GPU-sized step
+    return {"value": (args.n_rand + args.render_rays) / mix_t, "unit": "rays/s", "cores": cores, "kind": "port",
+            "train_rays_per_s": train_rps, "render_rays_per_s": render_rps,
+            "sample": f"train: {steps} steps x {b_train} rays ({t_train:.1f} s); render: {done} rays in {chunk}-ray chunks "
+                      f"({t_render:.1f} s); coarse 64" + (f" + fine 64+{NI}" if NI > 0 else "") + ", torch-CPU fp32 oracle; "
+                      f"value = rays of one GPU step (train {args.n_rand} + render {args.render_rays}) / CPU time for them",
+            "seconds": t_train + t_render}
+
+
+def cpu_baseline_ngp(args):
+    """configs[4] on the host cores: OracleNGP (hash grid 16 x 2^19 x 2 + SH3 + 2 x 64 MLP, autograd) training at
+    B = 1024 rays and a 65 536-ray render slice, time-boxed like cpu_baseline."""
+    from oracle import nerf_oracle as O
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    res = O.hashgrid_resolutions(16, 16, 2048)
+    g = torch.Generator().manual_seed(0)
+    tables = (torch.rand(16, 1 << 19, 2, generator=g) * 2 - 1) * 1e-4
+    ng = O.OracleNGP(tables, res, seed=4, n_samples=64)
+    b_train, n_render, chunk = 1024, 65536, 8192
+    o = torch.nn.functional.normalize(torch.randn(n_render, 3, generator=g), dim=-1) * 4.0
+    d = -o / 4.0 + 0.2 * torch.randn(n_render, 3, generator=g)
+    y = torch.rand(b_train, 3, generator=g)
+    ng.step(o[:b_train], d[:b_train], y)
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 20 and (steps < 3 or time.perf_counter() - t0 < 45.0):
+        ng.step(o[:b_train], d[:b_train], y)
+        steps += 1
+    t_train = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    done = 0
+    with torch.no_grad():
+        while done < n_render and (done < 2 * chunk or time.perf_counter() - t1 < 45.0):
+            ng.render(O.pack_rays(o[done:done + chunk], d[done:done + chunk], 2.0, 6.0))
+            done += chunk
+    t_render = time.perf_counter() - t1
+    train_rps, render_rps = b_train * steps / t_train, done / t_render
+    mix_t = args.n_rand / train_rps + args.render_rays / render_rps
+    return {"value": (args.n_rand + args.render_rays) / mix_t, "unit": "rays/s", "cores": cores, "kind": "port",
+            "train_rays_per_s": train_rps, "render_rays_per_s": render_rps,
+            "sample": f"train: {steps} steps x {b_train} rays ({t_train:.1f} s); render: {done} rays ({t_render:.1f} s); "
+                      "hash grid 16x2^19x2 + SH3 + 2x64, 64 samples/ray, torch-CPU fp32 oracle (OracleNGP)",
+            "seconds": t_train + t_render}
 
 
 if __name__ == "__main__":

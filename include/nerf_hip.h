@@ -62,7 +62,8 @@ int nerf_pixel_permutation(int64_t* out_idx, int64_t n, int64_t domain, uint64_t
 int nerf_ray_gen(const int64_t* pixel_idx, int64_t n, int H, int W, const double* K_host, const float* c2w_host,
                  float near, float far, float* rays, int64_t* coords, void* stream);
 
-/* out[i, :] = src[idx[i], :]   (target pixel gather, entrypoints/__test_nerf.py:236)  */
+/* out[i, :] = src[idx[i], :]   (target pixel gather, entrypoints/__test_nerf.py:236).
+ * idx[i] outside [0, n_src) is never dereferenced: that output row is NaN.               */
 int nerf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t n, int channels, float* out,
                      void* stream);
 
@@ -141,6 +142,17 @@ int nerf_composite_backward(const float* raw, const float* z, const float* rays,
 int nerf_mse_loss_grad(const float* pred, const float* target, int64_t count, float grad_scale, float* loss_out,
                        float* d_pred, void* stream);
 
+/* replaces: ops/metric.py:20-64 SSIM (unfinished upstream: the body stops after the five windowed moments; this is
+ * the formula those moments feed).  pred, gt: [N,C,H,W] float32 device; window_host: the 1-D window (w_size <= 33
+ * taps, the 2-D window of create_window :49-55 is its outer product), applied as a depthwise VALID convolution
+ * (padding = NO_PAD, :33-42).  sums: [N,2] float64 device, overwritten with
+ *   sums[n][0] = sum over (c, y, x) of ((2 mu_p mu_g + c1)(2 s_pg + c2)) / ((mu_p^2 + mu_g^2 + c1)(s_p^2 + s_g^2 + c2))
+ *   sums[n][1] = sum of the contrast-structure term (2 s_pg + c2) / (s_p^2 + s_g^2 + c2)
+ * over the C (H-w+1)(W-w+1) window positions of image n; the caller divides by that count.
+ * c1 = (0.01 L)^2, c2 = (0.03 L)^2 with the dynamic range L of :24-28 are computed by the caller.                 */
+int nerf_ssim_sums(const float* pred, const float* gt, int N, int C, int H, int W, const float* window_host,
+                   int w_size, float c1, float c2, double* sums, void* stream);
+
 /* ---------------------------------------------------------------- the MLP (a11, a12)
  * replaces: models/NeRF.py:160-243 (NeRF.__init__/forward), :10-48 (run_model),
  * models/embedding.py:4-21 (embed) for the architecture n_layers=8, width=256,
@@ -204,6 +216,19 @@ int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void*
  * models sit behind fixed encodings and return NERF_E_UNSUPPORTED.                                             */
 int nerf_mlp_backward_inputs(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,
                              int64_t M, void* dz, float* grads, float* d_x, void* stream);
+
+/* Test hook (no reference counterpart): one layer of the training stores of the last nerf_query_fused(acts != NULL)
+ * / nerf_mlp_backward call, decoded from the fragment-block layout to row-major float32 out[M, width], so that the
+ * parity tests can compare EVERY layer's activation and dZ with the oracle (and feed the kernel's own ReLU decisions
+ * to the oracle's backward).  8 x 256 view model only.
+ *   kind 0 (store = acts): layer 0..7 = relu(pos_l) (models/NeRF.py:221-222), 8 = feature (:231), 9 = relu(dir0)
+ *                          (:235-236), 10 = position encoding (64 = 63 + pad), 11 = direction encoding (32 = 27 + pad)
+ *   kind 1 (store = dz):   layer 0..7 = dL/d(pre-activation of pos_l), 8 = d feature, 9 = d dir0 pre-activation,
+ *                          10 = d alpha (column 0), 11 = d rgb (columns 0..2)
+ * nerf_mlp_debug_width returns `width` (16 x fragments) or -1.                                                     */
+int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int layer);
+int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store, int kind, int layer, int64_t M, float* out,
+                        void* stream);
 
 /* The same rows never leaving the chip: hash gathers + SH evaluated inside the 2 x 64 forward kernel (L = 16, F = 2,
  * sh_degree = 3; arch = {2, 64, 32, 16, -1, 1}) -> raw [B,n,4]; acts as in nerf_query_fused.  The table gradient of

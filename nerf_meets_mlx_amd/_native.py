@@ -33,6 +33,7 @@ SIGNATURES = {
     "nerf_composite_forward": (_I, [_P, _P, _P, _I64, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P]),
     "nerf_composite_backward": (_I, [_P, _P, _P, _I64, _I, _F, _P, _I, _P, _P, _P, _P, _P]),
     "nerf_mse_loss_grad": (_I, [_P, _P, _I64, _F, _P, _P, _P]),
+    "nerf_ssim_sums": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _F, _F, _P, _P]),
     "nerf_mlp_param_count": (_I64, [_P]),
     "nerf_mlp_packed_bytes": (_I64, [_P]),
     "nerf_mlp_pack": (_I, [_P, _P, _P, _P]),
@@ -43,6 +44,8 @@ SIGNATURES = {
     "nerf_query_fused": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
     "nerf_mlp_backward": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P]),
     "nerf_mlp_backward_inputs": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "nerf_mlp_debug_width": (_I, [_P, _I, _I]),
+    "nerf_mlp_debug_read": (_I, [_P, _P, _I, _I, _I64, _P, _P]),
     "nerf_render_workspace_bytes": (_I64, [_I64, _I, _I]),
     "nerf_render_rays_fused": (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_comm_unique_id": (_I, [C.c_char_p]),

@@ -25,11 +25,13 @@ class FusedQuery(torch.autograd.Function):
         if params.data_ptr() != model.params.data_ptr():
             model.load_flat(params.detach())
         ctx.model = model
-        return model.query(rays, z, ref_quirks=ref_quirks, train=True)
+        raw = model.query(rays, z, ref_quirks=ref_quirks, train=True)
+        ctx.generation = model.activation_generation()     # a second graph on the same model invalidates this one
+        return raw
 
     @staticmethod
     def backward(ctx, d_raw):
-        g = ctx.model.backward(d_raw.contiguous())
+        g = ctx.model.backward(d_raw.contiguous(), generation=ctx.generation)
         return g.clone(), None, None, None, None
 
 

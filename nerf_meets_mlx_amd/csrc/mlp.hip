@@ -1888,14 +1888,26 @@ static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: L
 static int g_ring_wgs = 0;       // persistent workgroups of the ring kernels; 0 = one per CU of the current device
 // CUs of the current device (256 on an MI355X in SPX mode), asked once: the persistent kernels and the dW split are
 // sized to it instead of to a constant
+// Per-device state: the CU count and the "dynamic LDS attribute set" flags belong to the CURRENT device (a process may
+// move between devices with hipSetDevice; hipFuncSetAttribute applies to the device that is current when it is called).
+constexpr int MAX_DEVICES = 64;
+static int cur_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+  return d;
+}
+struct DevOnce {
+  bool done[MAX_DEVICES] = {};
+  bool first() { const int d = cur_device(); if (done[d]) return false; done[d] = true; return true; }
+};
 static int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
+  static int n[MAX_DEVICES] = {};
+  const int dev = cur_device();
+  if (n[dev] == 0) {
+    int v = 0;
+    n[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
   }
-  return n;
+  return n[dev];
 }
 static inline int ring_wgs() { return g_ring_wgs > 0 ? g_ring_wgs : cu_count(); }
 
@@ -2013,10 +2025,9 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   if ((variant == 4 || variant == 5) && MODE == 1 && !acts) {
     const int64_t nsuper = (M + 255) / 256;
     const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs()));
-    static bool once16 = false;
-    if (!once16) {
+    static DevOnce once16;
+    if (once16.first()) {
       ensure_lds(mlp_fwd_ring16_kernel<8, 2>, RING16_LDS_BYTES); ensure_lds(mlp_fwd_ring16_kernel<4, 4>, RING16_LDS_BYTES);
-      once16 = true;
     }
     FwdArgs a16 = a;
     a16.wf = reinterpret_cast<const bf16x8*>(base + L::F16_OFFSET);
@@ -2027,8 +2038,8 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
   if (variant >= 3 && MODE == 1) {
     const int64_t nsuper = (ntiles + 7) / 8;
     const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), b(512);
-    static bool once = false;
-    if (!once) { ensure_lds(mlp_fwd_ring_kernel<1, true>, RING_LDS_BYTES); ensure_lds(mlp_fwd_ring_kernel<1, false>, RING_LDS_BYTES); once = true; }
+    static DevOnce once;
+    if (once.first()) { ensure_lds(mlp_fwd_ring_kernel<1, true>, RING_LDS_BYTES); ensure_lds(mlp_fwd_ring_kernel<1, false>, RING_LDS_BYTES); }
     if (acts) hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, true>), g, b, RING_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, false>), g, b, RING_LDS_BYTES, s, a);
     return check_launch("mlp forward (ring)");
@@ -2086,8 +2097,8 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     img_args(a, arch, packed);
     a.x = x; a.out = out; a.acts = acts; a.M = M;
     const int64_t nsuper = ((M + 31) / 32 + 7) / 8;
-    static bool once = false;
-    if (!once) { ensure_lds(mlp_img_fwd_ring_kernel<true>, RING_LDS_BYTES); ensure_lds(mlp_img_fwd_ring_kernel<false>, RING_LDS_BYTES); once = true; }
+    static DevOnce once;
+    if (once.first()) { ensure_lds(mlp_img_fwd_ring_kernel<true>, RING_LDS_BYTES); ensure_lds(mlp_img_fwd_ring_kernel<false>, RING_LDS_BYTES); }
     const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), b(512);
     if (acts) hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<true>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
@@ -2160,11 +2171,9 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
   d.ntiles = (int)ntiles; d.astride = astride; d.zstride = zstride;
   d.acts = acts; d.dz = dz; d.grads = grads;
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
+  static DevOnce lds_attr_set;
+  if (lds_attr_set.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-    lds_attr_set = true;
-  }
   hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
   return check_launch("mlp dW");
 }
@@ -2205,8 +2214,8 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     img_args(a, arch, packed);
     a.d_out = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M;
     const int64_t nsuper = (ntiles + 7) / 8;
-    static bool once_i = false;
-    if (!once_i) { ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES); once_i = true; }
+    static DevOnce once_i;
+    if (once_i.first()) ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES);
     hipLaunchKernelGGL(mlp_img_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
                        RING_LDS_BYTES, s, a);
     int rci = check_launch("mlp backward chain (image model)");
@@ -2233,8 +2242,8 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   const int variant = g_mlp_variant == 0 ? 3 : g_mlp_variant;
   if (variant >= 3) {
     const int64_t nsuper = (ntiles + 7) / 8;
-    static bool once = false;
-    if (!once) { ensure_lds(mlp_bwd_ring_kernel, RING_LDS_BYTES); once = true; }
+    static DevOnce once;
+    if (once.first()) ensure_lds(mlp_bwd_ring_kernel, RING_LDS_BYTES);
     if (g_bwd_stage != 2)
       hipLaunchKernelGGL(mlp_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
                          RING_LDS_BYTES, s, b);
@@ -2303,6 +2312,60 @@ extern "C" int nerf_mlp_backward_inputs(const nerf_mlp_arch* arch, const void* p
                                         void* stream) {
   NERF_REQUIRE(d_x, NERF_E_NULL, "nerf_mlp_backward_inputs: d_x is NULL");
   return mlp_backward_impl(arch, packed, acts, d_raw, M, dz, grads, d_x, stream);
+}
+
+// ---- test hook: one layer of the training stores (fragment blocks) as row-major fp32 ----------------------------
+namespace nerf {
+__global__ void __launch_bounds__(256) decode_frags_kernel(const void* base, int64_t stride16, int slot0, int nfrag,
+                                                           int64_t M, float* __restrict__ out) {
+  const int64_t total = M * nfrag * 2;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int h = (int)(t & 1), ks = (int)((t >> 1) % nfrag);
+    const int64_t m = t / (2 * nfrag);
+    const bf16x8 v = *frag_ptr(const_cast<void*>(base), m >> 5, stride16, slot0 + ks, (int)(m & 31), h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[m * (16 * nfrag) + kperm(ks, h, j)] = (float)v[j];
+  }
+}
+// (slot, fragments) of `layer` in the activation (kind 0) or dZ (kind 1) store of the 8 x 256 view model
+static bool debug_slot(int kind, int layer, int* slot, int* nfrag) {
+  if (layer < 0 || layer > 11) return false;
+  if (kind == 0) {
+    if (layer < 8) { *slot = L::A_H0 + 16 * layer; *nfrag = 16; }
+    else if (layer == 8) { *slot = L::A_FEAT; *nfrag = 16; }
+    else if (layer == 9) { *slot = L::A_HD; *nfrag = 8; }
+    else if (layer == 10) { *slot = L::A_PE; *nfrag = 4; }
+    else { *slot = L::A_DPE; *nfrag = 2; }
+    return true;
+  }
+  if (kind == 1) {
+    if (layer < 8) { *slot = L::Z_L0 + 16 * layer; *nfrag = 16; }
+    else if (layer == 8) { *slot = L::Z_F; *nfrag = 16; }
+    else if (layer == 9) { *slot = L::Z_D; *nfrag = 8; }
+    else if (layer == 10) { *slot = L::Z_A; *nfrag = 1; }
+    else { *slot = L::Z_RGB; *nfrag = 1; }
+    return true;
+  }
+  return false;
+}
+}  // namespace nerf
+
+extern "C" int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int layer) {
+  int slot = 0, nfrag = 0;
+  if (!arch_ok(arch) || !debug_slot(kind, layer, &slot, &nfrag)) return -1;
+  return 16 * nfrag;
+}
+
+extern "C" int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store, int kind, int layer, int64_t M,
+                                   float* out, void* stream) {
+  NERF_ARCH_CHECK("nerf_mlp_debug_read");
+  int slot = 0, nfrag = 0;
+  NERF_REQUIRE(debug_slot(kind, layer, &slot, &nfrag), NERF_E_SHAPE, "nerf_mlp_debug_read: kind must be 0/1 and layer 0..11");
+  NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");
+  if (M <= 0) return NERF_OK;
+  hipLaunchKernelGGL(decode_frags_kernel, dim3(grid_for(M * nfrag * 2, 256)), dim3(256), 0, as_stream(stream), store,
+                     kind == 0 ? astride16() : zstride16(), slot, nfrag, M, out);
+  return check_launch("nerf_mlp_debug_read");
 }
 
 #ifdef NERF_CLOCK_STAMP

@@ -79,12 +79,14 @@ __global__ void ray_gen_kernel(const int64_t* __restrict__ idx, int64_t n, int W
   }
 }
 
-__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, int C,
-                                   float* __restrict__ out) {
+// An index outside [0, n_src) never reads: its output row is NaN (the launch is asynchronous, so it cannot fail)
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t n_src, const int64_t* __restrict__ idx,
+                                   int64_t n, int C, float* __restrict__ out) {
   const int64_t total = n * C;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / C; const int c = (int)(t - i * C);
-    out[t] = src[idx[i] * C + c];
+    const int64_t row = idx[i];
+    out[t] = (row >= 0 && row < n_src) ? src[row * C + c] : __builtin_nanf("");
   }
 }
 
@@ -147,8 +149,8 @@ extern "C" int nerf_gather_rows(const float* src, int64_t n_src, const int64_t* 
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(src && idx && out, NERF_E_NULL, "nerf_gather_rows: NULL pointer");
   NERF_REQUIRE(n_src > 0, NERF_E_SHAPE, "nerf_gather_rows: empty source");
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * channels, 256)), dim3(256), 0, as_stream(stream), src, idx,
-                     n, channels, out);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * channels, 256)), dim3(256), 0, as_stream(stream), src, n_src,
+                     idx, n, channels, out);
   return check_launch("nerf_gather_rows");
 }
 

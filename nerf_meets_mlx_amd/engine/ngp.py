@@ -33,9 +33,15 @@ class _Flat:
 
     def __init__(self, params: torch.Tensor, grads: torch.Tensor):
         self.params, self.grads, self.n_params = params.view(-1), grads.view(-1), params.numel()
+        self.name = "tables"
 
     def mark_updated(self):
         pass
+
+    def load_flat(self, flat: torch.Tensor):
+        assert flat.numel() == self.n_params
+        with torch.no_grad():
+            self.params.copy_(flat.to(self.params.device, torch.float32).reshape(-1))
 
 
 class HashNeRF:
@@ -97,8 +103,7 @@ class HashNeRF:
         raw = torch.empty(B, n, 4, dtype=torch.float32, device=z.device)
         acts = None
         if train:
-            acts = m._workspace("acts", N.lib().nerf_mlp_acts_bytes(C.byref(m.arch), B * n))
-            m._acts_M = B * n
+            acts = m._begin_train_pass(B * n)
             self._pts, self._rz = None, (rays, z)
         N.check(N.lib().nerf_ngp_query_fused(C.byref(m.arch), N.ptr(m.packed()), N.ptr(rays), N.ptr(z), B, n,
                                              N.ptr(e.tables), e.n_levels, e.log2_hashmap_size, e.n_features_per_level,
@@ -139,6 +144,7 @@ class NGPTrainer(Trainer):
                          seed=seed, device=device, chunk=chunk)
         self.coarse = None                                   # the 8 x 256 network of the base class is not used
         self.field = HashNeRF(device=self.device, seed=seed, **hash_kw)
+        self.field.mlp.name = "mlp"
         # Adam WITH bias correction: without it the first steps are lr * sign(g), which turns bf16 noise in near-zero
         # table gradients into full-size steps and can drive sigma negative everywhere (a dead network under the
         # reference's un-activated sigma).  This loop is our wiring, so the choice is ours; lrate is
@@ -171,5 +177,7 @@ class NGPTrainer(Trainer):
             outs.append(render.composite(raw, z, r, 0.0, self.white_bkgd, need_weights=False)[0])
         return torch.cat(outs, 0)
 
-    def state_dict(self):
-        return {"it": self.it, "mlp": self.field.mlp.params.cpu(), "tables": self.field.enc.tables.cpu()}
+    def _checkpoint_buffers(self):
+        """Trainer.save / load / state_dict / load_state_dict work on these: the 2 x 64 MLP and the hash tables, with
+        their two Adam (m, v) pairs and step counts (bias correction is on here, so the counts matter)."""
+        return {"mlp": self.field.mlp, "tables": self.field.table}

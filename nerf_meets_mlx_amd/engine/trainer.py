@@ -14,6 +14,7 @@ importance sampler run as HIP kernels instead of numpy / torch-CPU, nothing leav
 with world_size > 1 each rank draws its own rays and the flat gradients are summed with ONE RCCL
 all-reduce per network step (mean over ranks).
 """
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -47,6 +48,9 @@ class Trainer:
                             device=self.device, seed=s)
         self.coarse = mk(seed)                                  # identical initial weights on every rank
         self.fine = mk(seed + 1) if N_importance > 0 else None
+        self.coarse.name = "coarse"                             # Adam state keys when the state is not shared
+        if self.fine is not None:
+            self.fine.name = "fine"
         self.opt = Adam(lrate, betas=(0.9, 0.999), shared_state=ref_quirks)
         self.it = 0
         self.gen = torch.Generator(device=self.device)
@@ -125,39 +129,79 @@ class Trainer:
         return float(10.0 * torch.log10(1.0 / mse))
 
     # ---------------------------------------------------------------- checkpoint
-    def state_dict(self):
-        sd = {"it": self.it, "coarse": self.coarse.params.cpu(), "adam": {k: [t.cpu() for t in v] for k, v in self.opt.state.items() if isinstance(k, str)}}
+    def _checkpoint_buffers(self):
+        """name -> object with `.params` (flat fp32 device buffer) and `.load_flat(t)`; the names are also the Adam keys."""
+        b = {"coarse": self.coarse}
         if self.fine is not None:
-            sd["fine"] = self.fine.params.cpu()
-        return sd
+            b["fine"] = self.fine
+        return b
 
-    def save(self, path: str):
-        """Flat-buffer checkpoint as .npz (the reference declares --i_weights / --ft_path but never implements them,
-        `models/NeRF.py:122-125`)."""
-        sd = self.state_dict()
-        arrays = {"it": np.array(sd["it"]), "coarse": sd["coarse"].numpy()}
-        if "fine" in sd:
-            arrays["fine"] = sd["fine"].numpy()
-        for k, (m, v) in sd["adam"].items():
-            arrays[f"adam_{k}_m"], arrays[f"adam_{k}_v"] = m.numpy(), v.numpy()
-        np.savez(path, **arrays)
-
-    def load(self, path: str):
-        z = np.load(path)
-        sd = {"it": int(z["it"]), "coarse": torch.from_numpy(z["coarse"]), "adam": {}}
-        if "fine" in z:
-            sd["fine"] = torch.from_numpy(z["fine"])
-        for k in z.files:
-            if k.startswith("adam_") and k.endswith("_m"):
-                name = k[5:-2]
-                sd["adam"][name] = [torch.from_numpy(z[k]), torch.from_numpy(z[f"adam_{name}_v"])]
-        self.load_state_dict(sd)
+    def state_dict(self):
+        """Everything a bit-identical continuation needs: iteration, flat parameters, Adam (m, v) + step counts per
+        state key, and the two host/device RNG streams (image choice, importance uniforms)."""
+        return {"it": self.it, "params": {k: m.params.detach().cpu().clone() for k, m in self._checkpoint_buffers().items()},
+                "adam": self.opt.state_dict(), "rng_numpy": self.rng.bit_generator.state,
+                "rng_torch": self.gen.get_state().clone()}
 
     def load_state_dict(self, sd):
         self.it = int(sd["it"])
-        self.coarse.load_flat(sd["coarse"])
-        if self.fine is not None and "fine" in sd:
-            self.fine.load_flat(sd["fine"])
-        for k, v in sd.get("adam", {}).items():
-            self.opt.state[k] = [t.to(self.device) for t in v]
-            self.opt.step_count.setdefault(k, 0)
+        bufs = self._checkpoint_buffers()
+        params = sd.get("params", {k: sd[k] for k in bufs if k in sd})       # round-1 layout: parameters at top level
+        missing = [k for k in bufs if k not in params]
+        if missing:
+            raise KeyError(f"checkpoint has no parameters for {missing} (has {sorted(params)})")
+        for k, m in bufs.items():
+            m.load_flat(params[k])
+        adam = sd.get("adam", {})
+        if "state" not in adam:                                              # round-1 layout: {key: [m, v]}
+            adam = {"state": adam, "step_count": {}}
+        self.opt.load_state_dict(adam, device=self.device)
+        if "rng_numpy" in sd:
+            self.rng.bit_generator.state = sd["rng_numpy"]
+        if "rng_torch" in sd:
+            self.gen.set_state(torch.as_tensor(sd["rng_torch"], dtype=torch.uint8).cpu())
+
+    @staticmethod
+    def _npz_path(path: str) -> str:
+        return path if path.endswith(".npz") else path + ".npz"
+
+    def save(self, path: str) -> str:
+        """Flat-buffer checkpoint as ONE .npz (the reference declares --i_weights / --ft_path / --no_reload but never
+        implements them, `models/NeRF.py:122-125`).  Returns the path written (".npz" is appended when missing, which is
+        also what load() does)."""
+        import json
+        sd = self.state_dict()
+        arrays = {"it": np.array(sd["it"], dtype=np.int64)}
+        for k, t in sd["params"].items():
+            arrays[f"params/{k}"] = t.numpy()
+        for k, (m, v) in sd["adam"]["state"].items():
+            arrays[f"adam/{k}/m"], arrays[f"adam/{k}/v"] = m.numpy(), v.numpy()
+            arrays[f"adam/{k}/steps"] = np.array(sd["adam"]["step_count"].get(k, 0), dtype=np.int64)
+        arrays["adam_lr"] = np.array(sd["adam"]["learning_rate"], dtype=np.float64)
+        arrays["rng_numpy_json"] = np.frombuffer(json.dumps(sd["rng_numpy"]).encode(), dtype=np.uint8)
+        arrays["rng_torch"] = sd["rng_torch"].numpy()
+        path = self._npz_path(path)
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, **arrays)
+        os.replace(tmp, path)                                   # never leave a half-written checkpoint under the final name
+        return path
+
+    def load(self, path: str):
+        import json
+        path = path if os.path.exists(path) else self._npz_path(path)
+        z = np.load(path)
+        sd = {"it": int(z["it"]), "params": {}, "adam": {"state": {}, "step_count": {}}}
+        for k in z.files:
+            if k.startswith("params/"):
+                sd["params"][k[7:]] = torch.from_numpy(z[k])
+            elif k.startswith("adam/") and k.endswith("/m"):
+                name = k[5:-2]
+                sd["adam"]["state"][name] = [torch.from_numpy(z[k]), torch.from_numpy(z[f"adam/{name}/v"])]
+                sd["adam"]["step_count"][name] = int(z[f"adam/{name}/steps"])
+        if "adam_lr" in z.files:
+            sd["adam"]["learning_rate"] = float(z["adam_lr"])
+        if "rng_numpy_json" in z.files:
+            sd["rng_numpy"] = json.loads(bytes(z["rng_numpy_json"]).decode())
+            sd["rng_torch"] = torch.from_numpy(z["rng_torch"].copy())
+        self.load_state_dict(sd)
+        return sd["it"]

@@ -16,10 +16,29 @@ from ..dataset.dataloader import load_blender_data, post_load_blender_data
 from ..engine.trainer import Trainer
 
 
+def checkpoint_dir(args) -> str:
+    """`{basedir}/{expname}` like nerf-pytorch, whose flags the reference keeps (config_parser.py:7-8)."""
+    return os.path.join(args.basedir, args.expname or "nerf")
+
+
+def latest_checkpoint(ckpt_dir: str) -> Optional[str]:
+    """Highest-numbered `{iteration:06d}.npz` in ckpt_dir, or None."""
+    if not os.path.isdir(ckpt_dir):
+        return None
+    names = sorted(f for f in os.listdir(ckpt_dir) if f.endswith(".npz") and f[:-4].isdigit())
+    return os.path.join(ckpt_dir, names[-1]) if names else None
+
+
 def main(path_dataset: Optional[str] = None, max_iter: int = 5000, device="cuda", ref_quirks: bool = True,
          hw_synthetic: int = 800, n_train_synthetic: int = 100, render_every: int = 50000, n_render_poses: int = 0,
-         log_every: int = 100, seed: int = 4):
-    args = config_parser.config_parser().parse_args(args=[])
+         log_every: int = 100, seed: int = 4, argv=None):
+    """argv: extra command-line flags of `config_parser` (e.g. ["--basedir", d, "--expname", "lego", "--i_weights",
+    "1000", "--ft_path", f, "--no_reload"]).  Checkpoint flags (config_parser.py:25-26,75; declared upstream, with
+    `models/NeRF.py:122-125` left as TODOs): every `--i_weights` iterations the trainer state goes to
+    `{basedir}/{expname}/{it:06d}.npz`; at start `--ft_path` (if given) or, unless `--no_reload`, the newest
+    checkpoint of that directory is loaded and training continues from its iteration.  In quirk mode a config file
+    forces no_reload like upstream does (config_parser.py:120)."""
+    args = config_parser.config_parser().parse_args(args=list(argv or []))
     if path_dataset is not None:
         configs = config_parser.load_config(None, os.path.join(path_dataset, "configs/lego.txt"))
         args = config_parser.update_NeRF_args(args, configs, ref_quirks=ref_quirks)
@@ -40,12 +59,19 @@ def main(path_dataset: Optional[str] = None, max_iter: int = 5000, device="cuda"
     tr = Trainer(train_imgs, train_poses, K, near=near, far=far, N_rand=args.N_rand, n_depth_samples=args.n_depth_samples,
                  N_importance=args.N_importance, lrate=args.lrate, lrate_decay=args.lrate_decay,
                  white_bkgd=bool(args.white_bkgd), ref_quirks=ref_quirks, seed=seed, device=device, chunk=args.chunk)
-    losses, frames = [], []
-    for i in range(1, max_iter + 1):
+    ckpt_dir = checkpoint_dir(args)
+    resume = args.ft_path if args.ft_path else (None if args.no_reload else latest_checkpoint(ckpt_dir))
+    if resume is not None:
+        tr.load(resume)
+    losses, frames, saved = [], [], []
+    for i in range(tr.it + 1, max_iter + 1):
         out = tr.train_step()
+        if args.i_weights and i % args.i_weights == 0 and tr.rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+            saved.append(tr.save(os.path.join(ckpt_dir, f"{i:06d}.npz")))
         if i % log_every == 0 or i == max_iter:
             losses.append((i, float(out["loss_coarse"]), float(out.get("loss_fine", torch.zeros(1)))))
         if render_every and i % render_every == 0:
             frames.append(tr.render_frame(train_poses[len(train_poses) // 2], shard=False).clamp(0, 1).cpu())
     video = [tr.render_frame(p, shard=False).clamp(0, 1).cpu() for p in render_poses[:n_render_poses]]
-    return {"trainer": tr, "losses": losses, "frames": frames, "video": video}
+    return {"trainer": tr, "losses": losses, "frames": frames, "video": video, "checkpoints": saved, "resumed_from": resume}

@@ -60,7 +60,12 @@ class NeRF:
         self.grads = torch.zeros_like(self.params)
         self._packed = None
         self._dirty = True
+        self._packed_version = -1           # params._version the packed image was built from
         self._ws: Dict[str, torch.Tensor] = {}
+        self.name: Optional[str] = None     # stable key for optimiser state / checkpoints ("coarse", "fine", ...)
+        self._gen = 0                       # generation of the activation workspace (one per train-mode forward)
+        self._acts_gen = -1
+        self._acts_M = -1
 
     # ---- parameter views (the reference's tree: list_linears_pos / list_linears_dir / ... ) ----
     def parameters(self) -> Dict[str, object]:
@@ -91,6 +96,9 @@ class NeRF:
     def mark_updated(self):
         self._dirty = True
 
+    def activation_generation(self) -> int:
+        return self._acts_gen
+
     # ---- packed bf16 fragment image ------------------------------------------------------------
     def packed(self) -> torch.Tensor:
         lib = N.lib()
@@ -101,10 +109,21 @@ class NeRF:
                                  "width=256, skips=[4] with in=63+27 + view head, or in=40 without view head and out<=4; n_layers=2, "
                                  "width=64, skips=[] with in=32+16 + view head)")
             self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        if self._dirty:
+        # re-pack when the master parameters changed: kernels that write through raw pointers (Adam) say so with
+        # mark_updated(); torch in-place ops on `params` or on the views of parameters() bump the version counter
+        if self._dirty or self.params._version != self._packed_version:
             N.check(lib.nerf_mlp_pack(C.byref(self.arch), N.ptr(self.params), N.ptr(self._packed), N.stream()))
             self._dirty = False
+            self._packed_version = self.params._version
         return self._packed
+
+    def _begin_train_pass(self, M: int) -> torch.Tensor:
+        """The ONE activation workspace of this model, stamped with a new generation: a later train-mode forward
+        overwrites it, and backward() refuses a generation that is no longer the stored one."""
+        acts = self._workspace("acts", N.lib().nerf_mlp_acts_bytes(C.byref(self.arch), M))
+        self._gen += 1
+        self._acts_gen, self._acts_M = self._gen, M
+        return acts
 
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         t = self._ws.get(key)
@@ -122,8 +141,7 @@ class NeRF:
         out = torch.empty(M, self.out_dim, dtype=torch.float32, device=x.device)
         acts = None
         if train:
-            acts = self._workspace("acts", N.lib().nerf_mlp_acts_bytes(C.byref(self.arch), M))
-            self._acts_M = M
+            acts = self._begin_train_pass(M)
         N.check(N.lib().nerf_mlp_forward_train(C.byref(self.arch), N.ptr(self.packed()), N.ptr(x), M, N.ptr(out),
                                                N.ptr(acts), N.stream()))
         return out
@@ -136,19 +154,25 @@ class NeRF:
         raw = torch.empty(B, n, 4, dtype=torch.float32, device=z.device)
         acts = None
         if train:
-            acts = self._workspace("acts", N.lib().nerf_mlp_acts_bytes(C.byref(self.arch), B * n))
-            self._acts_M = B * n
+            acts = self._begin_train_pass(B * n)
         N.check(N.lib().nerf_query_fused(C.byref(self.arch), N.ptr(self.packed()), N.ptr(rays), N.ptr(z), B, n,
                                          0 if ref_quirks else 1, N.ptr(raw), N.ptr(acts), N.stream()))
         return raw
 
-    def backward(self, d_raw: torch.Tensor, need_input_grad: bool = False):
+    def backward(self, d_raw: torch.Tensor, need_input_grad: bool = False, generation: Optional[int] = None):
         """Parameter gradients of the last `query / forward(..., train=True)`; overwrites self.grads.
         need_input_grad (2 x 64 model only): also returns dL/d(position features) [M, channel_input] for a trainable
-        encoder in front of the network (the hash grid)."""
+        encoder in front of the network (the hash grid).
+        generation: the value of `activation_generation()` right after the forward this gradient belongs to; when a
+        later train-mode forward of the same model has replaced the stored activations this raises instead of returning
+        gradients of the wrong graph."""
         d_raw = N.f32(d_raw)
         M = d_raw.numel() // self.out_dim
-        assert M == getattr(self, "_acts_M", -1), "backward() needs a matching query/forward(train=True) first"
+        if generation is not None and generation != self._acts_gen:
+            raise RuntimeError(f"NeRF.backward: the activations of forward #{generation} were overwritten by train-mode "
+                               f"forward #{self._acts_gen} of the same model (one activation workspace per model: run "
+                               "backward before the next train-mode forward, or use a second model object)")
+        assert M == self._acts_M, "backward() needs a matching query/forward(train=True) first"
         dz = self._workspace("dz", N.lib().nerf_mlp_dz_bytes(C.byref(self.arch), M))
         if need_input_grad:
             d_x = torch.empty(M, self.channel_input_pos, dtype=torch.float32, device=d_raw.device)
@@ -158,6 +182,19 @@ class NeRF:
         N.check(N.lib().nerf_mlp_backward(C.byref(self.arch), N.ptr(self.packed()), N.ptr(self._ws["acts"]),
                                           N.ptr(d_raw), M, N.ptr(dz), N.ptr(self.grads), N.stream()))
         return self.grads
+
+
+def debug_layer(model: NeRF, kind: str, layer: int) -> torch.Tensor:
+    """Test hook (`nerf_mlp_debug_read`): the stored activation ("acts") or dZ ("dz") of `layer` from the model's last
+    train-mode forward / backward as a row-major [M, width] float32 tensor."""
+    k = {"acts": 0, "dz": 1}[kind]
+    w = N.lib().nerf_mlp_debug_width(C.byref(model.arch), k, layer)
+    if w < 0:
+        raise ValueError("debug_layer: 8 x 256 view model only, kind acts|dz, layer 0..11")
+    M = model._acts_M
+    out = torch.empty(M, w, dtype=torch.float32, device=model.device)
+    N.check(N.lib().nerf_mlp_debug_read(C.byref(model.arch), N.ptr(model._ws[kind]), k, layer, M, N.ptr(out), N.stream()))
+    return out
 
 
 class Adam:
@@ -171,22 +208,44 @@ class Adam:
         self.learning_rate = learning_rate
         self.betas, self.eps = betas, eps
         self.bias_correction, self.shared_state = bias_correction, shared_state
-        self.state: Dict[object, List[torch.Tensor]] = {}
-        self.step_count: Dict[object, int] = {}
+        self.state: Dict[str, List[torch.Tensor]] = {}
+        self.step_count: Dict[str, int] = {}
+        self._auto_names: Dict[int, str] = {}
+
+    def key_of(self, model) -> str:
+        """State key: "shared" (Q7), else the model's `name`, else "model<k>" in order of first use -- never id(),
+        so that a checkpoint written by one process can be read by another."""
+        if self.shared_state:
+            return "shared"
+        name = getattr(model, "name", None)
+        if name:
+            return str(name)
+        return self._auto_names.setdefault(id(model), f"model{len(self._auto_names)}")
 
     def update(self, model: NeRF, grads: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
         g = model.grads if grads is None else grads
-        key = "shared" if self.shared_state else id(model)
+        key = self.key_of(model)
         if key not in self.state:
             self.state[key] = [torch.zeros_like(model.params), torch.zeros_like(model.params)]
-            self.step_count[key] = 0
-        self.step_count[key] += 1
+        self.step_count[key] = self.step_count.get(key, 0) + 1
         m, v = self.state[key]
         N.check(N.lib().nerf_adam_step(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
                                        float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
                                        float(self.eps), int(self.bias_correction), self.step_count[key],
                                        float(grad_scale), N.stream()))
         model.mark_updated()
+
+    def state_dict(self) -> Dict[str, object]:
+        return {"state": {k: [t.detach().cpu() for t in v] for k, v in self.state.items()},
+                "step_count": dict(self.step_count), "learning_rate": float(self.learning_rate)}
+
+    def load_state_dict(self, sd, device="cuda"):
+        self.state = {k: [t.to(device, torch.float32).contiguous().clone() for t in v] for k, v in sd["state"].items()}
+        self.step_count = {k: int(v) for k, v in sd.get("step_count", {}).items()}
+        for k in self.state:
+            self.step_count.setdefault(k, 0)
+        if "learning_rate" in sd:
+            self.learning_rate = float(sd["learning_rate"])
 
 
 def inference_wrapper_batch(model, chunk):

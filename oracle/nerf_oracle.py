@@ -18,8 +18,12 @@ Pinning status (see DESIGN.md "Oracle"):
     reference call sites: PARITY UNPINNED at the MLX boundary (mlx is not installable
     here; the reference has no tests / golden vectors of its own).
 
-All functions take/return torch CPU tensors.  `dtype` defaults to float32 (the
+All functions take/return torch tensors, CPU by default.  `dtype` defaults to float32 (the
 reference's dtype); float64 gives the "exact" value used to bound float tolerances.
+The functions are device-agnostic (they create tensors on the device of their inputs), so
+the long PSNR-parity runs (tools/psnr_parity.py) can run this restatement in fp32 on the
+torch-ROCm device -- still as the checker, never as the product; the CPU is what
+`cpu_baseline` times and what the golden fixtures were checked on.
 """
 from __future__ import annotations
 
@@ -87,25 +91,25 @@ def decompose_ray_batch(rays):
 # a5 / a6 / a7  depth sampling
 # --------------------------------------------------------------------------------------
 
-def mlx_linspace(start: float, stop: float, num: int, dtype=torch.float32):
+def mlx_linspace(start: float, stop: float, num: int, dtype=torch.float32, device=None):
     """mx.linspace as published for mlx 0.7.0 (mlx/ops.cpp, not in /root/reference):
     arange(0,num,float32) * float32((stop-start)/(num-1)) + start.  Differs from
     torch.linspace (symmetric formula) by <= 1 ulp; UNPINNED assumption."""
     step = np.float32((stop - start) / (num - 1)) if dtype == torch.float32 else (stop - start) / (num - 1)
-    seq = torch.arange(0, num, dtype=dtype)
-    return seq * torch.tensor(step, dtype=dtype) + torch.tensor(start, dtype=dtype)
+    seq = torch.arange(0, num, dtype=dtype, device=device)
+    return seq * torch.tensor(step, dtype=dtype, device=device) + torch.tensor(start, dtype=dtype, device=device)
 
 
 def sample_z_uniform(near, far, n: int):
     """sampling/uniform.py:7-18: t = linspace(0,1,n); z = near*(1-t) + far*t."""
-    t = mlx_linspace(0.0, 1.0, n, dtype=near.dtype)
+    t = mlx_linspace(0.0, 1.0, n, dtype=near.dtype, device=near.device)
     return near * (1.0 - t) + far * t
 
 
 def sample_z_lindisp(near, far, n: int):
     """sampling/linear_disparity.py:8-19, restated literally (both
     end points evaluate to 1/(x + inf) = 0; this is NOT the standard formula)."""
-    t = mlx_linspace(0.0, 1.0, n, dtype=near.dtype)
+    t = mlx_linspace(0.0, 1.0, n, dtype=near.dtype, device=near.device)
     return 1.0 / (1.0 / (near * (1.0 - t)) + 1.0 / (far * t))
 
 
@@ -126,18 +130,18 @@ def add_noise_z(z, strength: float, t_rand: Optional[torch.Tensor] = None):
 # a9 / a10  positional encodings
 # --------------------------------------------------------------------------------------
 
-def embedder_freqs(n_freqs: int, ref_quirks: bool = True, dtype=torch.float32):
+def embedder_freqs(n_freqs: int, ref_quirks: bool = True, dtype=torch.float32, device=None):
     """models/embedding.py:46-49: linspace(0, L-1, L) ** 2  (k^2, NOT 2^k: SURVEY Q4).
     ref_quirks=False gives the intended 2 ** linspace(0, L-1, L)."""
-    lin = torch.linspace(0.0, float(n_freqs - 1), n_freqs, dtype=dtype)
-    return lin ** 2.0 if ref_quirks else 2.0 ** lin
+    lin = torch.linspace(0.0, float(n_freqs - 1), n_freqs, dtype=dtype)       # on the host: identical values on any device
+    return (lin ** 2.0 if ref_quirks else 2.0 ** lin).to(device)
 
 
 def embedder(x, n_freqs: int, ref_quirks: bool = True):
     """models/embedding.py:30-71: [x, sin(f0 x), cos(f0 x), sin(f1 x), cos(f1 x), ...]
     each block in_dim wide; include_input truthy for 3-d inputs (:79)."""
     outs = [x]
-    for f in embedder_freqs(n_freqs, ref_quirks, x.dtype):
+    for f in embedder_freqs(n_freqs, ref_quirks, x.dtype, x.device):
         outs.append(torch.sin(x * f))
         outs.append(torch.cos(x * f))
     return torch.cat(outs, dim=-1)
@@ -157,7 +161,7 @@ def sinusoidal_freqs(n_freqs: int, min_exp=None, max_exp=None, dtype=torch.float
     """encoding/sinusoidal.py:27-28,49-51: 2 ** linspace(min_exp or 0, max_exp or n-1, n)."""
     mn = min_exp if min_exp else 0.0
     mx_ = max_exp if max_exp else float(n_freqs - 1)
-    return 2.0 ** mlx_linspace(mn, mx_, n_freqs, dtype=dtype)
+    return 2.0 ** mlx_linspace(mn, mx_, n_freqs, dtype=dtype)              # host values; callers move them
 
 
 def sinusoidal_encoding(x, n_freqs: int, min_exp: Optional[float] = None, max_exp: Optional[float] = None,
@@ -165,7 +169,7 @@ def sinusoidal_encoding(x, n_freqs: int, min_exp: Optional[float] = None, max_ex
     """encoding/sinusoidal.py:13-66: freq = 2 ** linspace(min,max,n); s = x[...,None]*freq
     reshaped dim-major/freq-minor; out = sin(concat[s, s + pi/2]); raw input appended
     at the END.  (`min_exp if min_exp else 0.0`, `max_exp if max_exp else n-1`: :27-28)."""
-    freq = sinusoidal_freqs(n_freqs, min_exp, max_exp, x.dtype)
+    freq = sinusoidal_freqs(n_freqs, min_exp, max_exp, x.dtype).to(x.device)
     s = (x[..., None] * freq).reshape(x.shape[0], -1)
     out = torch.sin(torch.cat([s, s + math.pi / 2.0], dim=-1))
     if include_input:
@@ -316,39 +320,98 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(x.dtype)
 
 
-def nerf_forward(arch: NerfArch, p, x, emulate_bf16: bool = False):
+class _RoundBothBF16(torch.autograd.Function):
+    """Value AND incoming gradient rounded to bf16 (what `x.to(bf16).to(f32)` does under torch autograd, written out).
+    On a layer input this is the kernel's arithmetic: the forward operand is bf16, and the gradient arriving here --
+    dH = W^T dZ_next, which the ReLU mask then turns into this layer's dZ -- is stored as bf16 by the backward chain
+    (csrc/mlp.hip: finish_quarter_bwd).  Mask-then-round equals round-then-mask."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    """Identity whose incoming gradient is rounded to bf16: the kernel's first dZ (d_raw -> bf16 rows of the rgb / alpha
+    jobs, csrc/mlp.hip: bwd_tiles)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+def _bf16_value_only(w):
+    """bf16-rounded value, straight-through gradient: the weight operand is bf16 but its gradient is accumulated and
+    kept in fp32 (mlp_dw_kernel's accumulators), not rounded."""
+    return w + (_bf16(w) - w).detach()
+
+
+def nerf_forward(arch: NerfArch, p, x, emulate_bf16: bool = False, masks: Optional[Dict[str, torch.Tensor]] = None,
+                 taps: Optional[Dict[str, torch.Tensor]] = None):
     """models/NeRF.py:201-243.  nn.Linear = x @ W.T + b.  Every pos layer is followed by
     ReLU; after layer idx in skips, h = concat[input_pos, h]; view head: alpha=Linear(h),
     feature=Linear(h) (no activation), h=ReLU(Linear([feature, input_dir])), rgb=Linear(h);
     output [rgb, alpha] raw (no sigmoid / ReLU).
     emulate_bf16: round MFMA operands (weights, layer inputs) to bf16 exactly where the
-    HIP kernel does, keep fp32 accumulation -- used to separate "bf16 by design" from bugs."""
-    r = _bf16 if emulate_bf16 else (lambda t: t)
-    lin = lambda h, n: r(h) @ r(p[n][0]).T + p[n][1]
+    HIP kernel does, keep fp32 accumulation, and in the backward round every dZ_l to bf16
+    like the kernel's chain does (each layer input is rounded ONCE, so a tensor with two
+    consumers -- h7 feeding alpha and feature -- gets the sum of both gradients rounded once,
+    like dZ7) -- used to separate "bf16 by design" from bugs.
+    masks (tests): {layer: bool [M, width]} replaces the ReLU decision of that layer
+    (h = z * mask), so that a gradient comparison is not dominated by units whose
+    pre-activation is ~0 and lands on the other side of zero in another implementation.
+    taps (tests): dict that receives every layer's post-activation output."""
+    r = _RoundBothBF16.apply if emulate_bf16 else (lambda t: t)
+    rw = _bf16_value_only if emulate_bf16 else (lambda t: t)
+    lin = lambda hr, n: hr @ rw(p[n][0]).T + p[n][1]
+
+    def act(zz, name):
+        out = zz * masks[name].to(zz.dtype) if masks is not None and name in masks else torch.relu(zz)
+        if taps is not None:
+            taps[name] = out
+        return out
+
     if arch.use_viewdirs:
         input_pos, input_dir = x[..., :arch.cin], x[..., arch.cin:]
     else:
         input_pos, input_dir = x, None
     h = input_pos
     for i in range(arch.D):
-        h = torch.relu(lin(h, f"pos{i}"))
+        h = act(lin(r(h), f"pos{i}"), f"pos{i}")
         if i in arch.skips:
             h = torch.cat([input_pos, h], dim=-1)
+    hr = r(h)
     if arch.use_viewdirs:
-        alpha = lin(h, "alpha")
-        feature = lin(h, "feature")
-        h = torch.relu(lin(torch.cat([feature, input_dir], dim=-1), "dir0"))
-        rgb = lin(h, "rgb")
-        return torch.cat([rgb, alpha], dim=-1)
-    return lin(h, "output")
+        alpha = lin(hr, "alpha")
+        feature = lin(hr, "feature")
+        if taps is not None:
+            taps["feature"] = feature
+        h = act(lin(r(torch.cat([feature, input_dir], dim=-1)), "dir0"), "dir0")
+        rgb = lin(r(h), "rgb")
+        out = torch.cat([rgb, alpha], dim=-1)
+    else:
+        out = lin(hr, "output")
+    return _RoundGradBF16.apply(out) if emulate_bf16 else out
 
 
-def run_model(arch, p, pos, dirs, netchunk: int = 65536, ref_quirks: bool = True, emulate_bf16: bool = False):
-    """models/NeRF.py:10-48: assert rank 3; embed all points; forward in `netchunk` slices."""
+def run_model(arch, p, pos, dirs, netchunk: int = 65536, ref_quirks: bool = True, emulate_bf16: bool = False,
+              masks=None, taps=None):
+    """models/NeRF.py:10-48: assert rank 3; embed all points; forward in `netchunk` slices.
+    masks / taps (tests, see nerf_forward) need the whole batch in one slice."""
     assert pos.dim() == 3, f"pos.shape={tuple(pos.shape)} should be [n_rays, n_depth_samples, 3]"
     B, n = pos.shape[:2]
     x = embed(pos, dirs, ref_quirks=ref_quirks)
-    outs = [nerf_forward(arch, p, x[i:i + netchunk], emulate_bf16) for i in range(0, x.shape[0], netchunk)]
+    if masks is not None or taps is not None:
+        assert x.shape[0] <= netchunk, "masks / taps: one netchunk slice only"
+    outs = [nerf_forward(arch, p, x[i:i + netchunk], emulate_bf16, masks, taps) for i in range(0, x.shape[0], netchunk)]
     out = torch.cat(outs, 0)
     return out.reshape(B, n, out.shape[-1])
 
@@ -374,7 +437,7 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std: float = 0.0, white_bkgd: boo
     x = (deltas * sigma)[..., None]                                  # [B,n,1]
     alphas = 1.0 - torch.exp(-torch.relu(x))
     T = torch.cumsum(x[..., :-1, :], dim=-2)
-    T = torch.cat([torch.zeros((*T.shape[:1], 1, 1), dtype=T.dtype), T], dim=-2)      # render.py:72-78
+    T = torch.cat([torch.zeros((*T.shape[:1], 1, 1), dtype=T.dtype, device=T.device), T], dim=-2)      # render.py:72-78
     T = torch.exp(-T)
     weights = alphas * T
     rgb = (weights * raw_rgb).sum(-2)
@@ -493,6 +556,47 @@ def psnr(pred, gt):
     return 10.0 * torch.log10(1.0 / mse(pred, gt))
 
 
+def ssim_window(w_size: int = 11, sigma: float = 1.5, ref_quirks: bool = True, dtype=torch.float32):
+    """ops/metric.py:57-64 `gaussian`: [exp(-(x - w//2)**2) / (2 sigma**2)] / sum -- as committed the division is
+    outside the exponential and cancels in the normalisation (effective window exp(-(x-c)^2)); ref_quirks=False is
+    the textbook exp(-(x-c)^2 / (2 sigma^2))."""
+    c = w_size // 2
+    if ref_quirks:
+        g = [math.exp(-(x - c) ** 2) / float(2 * sigma ** 2) for x in range(w_size)]
+    else:
+        g = [math.exp(-(x - c) ** 2 / float(2 * sigma ** 2)) for x in range(w_size)]
+    g = torch.tensor(g, dtype=torch.float64)
+    return (g / g.sum()).to(dtype)
+
+
+def ssim(pred, gt, w_size: int = 11, size_average: bool = True, full: bool = False, ref_quirks: bool = True):
+    """ops/metric.py:20-55 (SSIM.__call__ + create_window), with the part the reference leaves as "# TODO" (:44)
+    completed by the formula its five moments exist for (Wang et al. 2004, the pytorch-ssim code the body follows):
+    L from pred's range (:24-28); c1 = (0.01 L)^2, c2 = (0.03 L)^2; window = outer(g, g) per channel (:49-55);
+    depthwise conv2d with padding 0 (:33-42); ssim_map = (2 mu_p mu_g + c1)(2 s_pg + c2) / ((mu_p^2 + mu_g^2 + c1)
+    (s_p^2 + s_g^2 + c2)); mean over everything (size_average) or per image; full -> (ssim, cs)."""
+    import torch.nn.functional as F
+    _max = 255 if float(pred.max()) > 128 else 1
+    _min = -1 if float(pred.min()) < -0.5 else 0
+    L = _max - _min
+    c1, c2 = (0.01 * L) ** 2, (0.03 * L) ** 2
+    _, channel, height, width = pred.shape
+    g = ssim_window(w_size, 1.5, ref_quirks, pred.dtype).to(pred.device)
+    window = (g[:, None] @ g[None, :])[None, None].expand(channel, 1, w_size, w_size).contiguous()
+    conv = lambda t: F.conv2d(t, window, padding=0, groups=channel)
+    mu_p, mu_g = conv(pred), conv(gt)
+    mu_pp, mu_gg, mu_pg = mu_p * mu_p, mu_g * mu_g, mu_p * mu_g
+    s_pp, s_gg, s_pg = conv(pred * pred) - mu_pp, conv(gt * gt) - mu_gg, conv(pred * gt) - mu_pg
+    v1, v2 = 2.0 * s_pg + c2, s_pp + s_gg + c2
+    cs_map = v1 / v2
+    ssim_map = ((2.0 * mu_pg + c1) * v1) / ((mu_pp + mu_gg + c1) * v2)
+    if size_average:
+        ret, cs = ssim_map.mean(), cs_map.mean()
+    else:
+        ret, cs = ssim_map.mean(dim=(1, 2, 3)), cs_map.mean(dim=(1, 2, 3))
+    return (ret, cs) if full else ret
+
+
 def adam_step(p, g, m, v, lr: float, b1=0.9, b2=0.999, eps=1e-8, bias_correction=False, step: int = 1):
     """mlx.optimizers.Adam.apply_single (mlx 0.7.0; not in /root/reference):
     m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * m / (sqrt(v) + eps).
@@ -557,12 +661,12 @@ class OracleTrainer:
     fine step -> Adam (same optimiser: shared m/v in quirk mode, Q7) -> lr update."""
 
     def __init__(self, arch: NerfArch, n_samples=64, n_importance=128, lrate=5e-4, lrate_decay=500, seed=0,
-                 ref_quirks=True, emulate_bf16=False, near=2.0, far=6.0):
+                 ref_quirks=True, emulate_bf16=False, near=2.0, far=6.0, device="cpu"):
         self.arch, self.n, self.N = arch, n_samples, n_importance
         self.lrate, self.decay, self.lr = lrate, lrate_decay, lrate
         self.q, self.emu, self.near, self.far = ref_quirks, emulate_bf16, near, far
-        self.pc = flatten_params(arch, init_params(arch, seed)).requires_grad_(True)
-        self.pf = flatten_params(arch, init_params(arch, seed + 1)).requires_grad_(True) if n_importance > 0 else None
+        self.pc = flatten_params(arch, init_params(arch, seed)).to(device).requires_grad_(True)
+        self.pf = flatten_params(arch, init_params(arch, seed + 1)).to(device).requires_grad_(True) if n_importance > 0 else None
         self.m = [torch.zeros_like(self.pc), torch.zeros_like(self.pc)]
         self.m2 = self.m if ref_quirks else [torch.zeros_like(self.pc), torch.zeros_like(self.pc)]
         self.it = 0

@@ -256,3 +256,90 @@ def test_oracle_trainer_runs_and_learns():
         l = tr.step(o, d, y, u)
     assert l["loss_coarse"] < l0["loss_coarse"] and "loss_fine" in l
     assert tr.m2 is tr.m                      # Q7 shared Adam state in quirk mode
+
+
+def _grads_of(arch, flat, B, n, eps, masks=None, emulate=True):
+    torch.manual_seed(1000 * B + n)
+    g = torch.Generator().manual_seed(77)
+    o = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1) * 4.0
+    d = -o / 4.0 + 0.25 * torch.randn(B, 3, generator=g)
+    rays = O.pack_rays(o, d, 2.0, 6.0)
+    z = torch.sort(torch.rand(B, n) * 4 + 2, -1).values
+    up = torch.randn(B, n, 4)
+    fl = flat.clone().requires_grad_(True)
+    ro, rd, _, _, vd = O.decompose_ray_batch(rays)
+    pos = ro[:, None, :] + z[:, :, None] * rd[:, None, :]
+    pos = pos * (1 + eps * torch.randn_like(pos))
+    taps = {}
+    out = O.run_model(arch, O.unflatten_params(arch, fl), pos, vd, emulate_bf16=emulate, masks=masks, taps=taps)
+    (out * up).sum().backward()
+    return fl.grad, {k: v.detach() > 0 for k, v in taps.items() if k != "feature"}
+
+
+def test_oracle_gradient_noise_floor():
+    """Why the GPU gradient check is mask-aligned: with bf16 operands a 3e-7 relative nudge of the sample positions
+    (about 2 ulp) flips the ReLU decision of units whose pre-activation is ~0, and under a random-signed upstream
+    gradient the oracle's OWN dW then moves by ~1 % (no averaging: the sum over samples is incoherent).  With the ReLU
+    decisions held fixed (masks=...) the same nudge moves it by < 0.2 %.  Any second bf16 implementation (the HIP
+    kernels: different fp32 summation order, hardware sin) sits at the first number unless the masks are aligned."""
+    arch = O.NerfArch()
+    flat = O.flatten_params(arch, O.init_params(arch, 3)) * 1.5
+    a, masks = _grads_of(arch, flat, 6, 40, 0.0)
+    b, _ = _grads_of(arch, flat, 6, 40, 3e-7)
+    c, _ = _grads_of(arch, flat, 6, 40, 3e-7, masks=masks)
+    a2, _ = _grads_of(arch, flat, 6, 40, 0.0, masks=masks)
+    rel = lambda x, y: float((x - y).norm() / y.norm())
+    assert torch.equal(a, a2)                      # masks taken from the run itself change nothing
+    assert rel(b, a) > 4e-3                        # free-running: percent-level self-disagreement
+    assert rel(c, a) < 2e-3 and rel(c, a) < 0.25 * rel(b, a)
+
+
+def test_oracle_bf16_emulation_rounds_gradients_like_the_kernel():
+    """emulate_bf16 rounds, in the backward, exactly what the HIP chain stores as bf16: every dZ (gradient arriving at a
+    layer input, rounded once even with two consumers) and d_raw; weight gradients stay fp32 (not bf16 values)."""
+    arch = O.NerfArch()
+    flat = O.flatten_params(arch, O.init_params(arch, 1)) * 1.5
+    fl = flat.clone().requires_grad_(True)
+    x = torch.randn(50, 90, generator=torch.Generator().manual_seed(0))
+    taps = {}
+    out = O.nerf_forward(arch, O.unflatten_params(arch, fl), x, emulate_bf16=True, taps=taps)
+    for t in taps.values():
+        t.retain_grad()
+    (out * torch.randn(50, 4, generator=torch.Generator().manual_seed(1))).sum().backward()
+    is_bf16 = lambda t: torch.equal(t, t.to(torch.bfloat16).to(torch.float32))
+    for name in ("pos0", "pos4", "pos7", "feature", "dir0"):
+        assert is_bf16(taps[name].grad), name
+    assert not is_bf16(fl.grad)                    # dW accumulated in fp32, like mlp_dw_kernel's accumulators
+    # forward values are what they were before the masks / taps / rounding-aware rewrite: bf16 operands, fp32 accumulate
+    p = O.unflatten_params(arch, flat)
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    h = torch.relu(r(x[:, :63]) @ r(p["pos0"][0]).T + p["pos0"][1])
+    np.testing.assert_allclose(taps["pos0"].detach().numpy(), h.numpy(), rtol=0, atol=0)
+
+
+def test_kat_ssim():
+    """SSIM closed forms: identical images -> 1; constant images a, b -> (2ab + c1) / (a^2 + b^2 + c1) (all variances
+    zero, cs = 1); the quirk window is exp(-(x-5)^2) normalised (the /(2 sigma^2) cancels), the intended one a sigma-1.5
+    Gaussian; dynamic range switches to 255 when max(pred) > 128 (ops/metric.py:24-28)."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 24, 24, generator=g)
+    assert abs(float(O.ssim(x, x)) - 1.0) < 1e-6
+    a, b = torch.full((1, 1, 16, 16), 0.3, dtype=torch.float64), torch.full((1, 1, 16, 16), 0.6, dtype=torch.float64)
+    s, cs = O.ssim(a, b, full=True)              # float64: in float32 the "zero" variances are ~1e-8 against c2 = 9e-4
+    c1 = 0.01 ** 2
+    assert abs(float(s) - (2 * 0.3 * 0.6 + c1) / (0.09 + 0.36 + c1)) < 1e-6 and abs(float(cs) - 1.0) < 1e-6
+    wq = O.ssim_window(11, 1.5, True, torch.float64)
+    e = torch.exp(-(torch.arange(11, dtype=torch.float64) - 5) ** 2)
+    np.testing.assert_allclose(wq.numpy(), (e / e.sum()).numpy(), rtol=1e-12)
+    wi = O.ssim_window(11, 1.5, False, torch.float64)
+    e2 = torch.exp(-(torch.arange(11, dtype=torch.float64) - 5) ** 2 / 4.5)
+    np.testing.assert_allclose(wi.numpy(), (e2 / e2.sum()).numpy(), rtol=1e-12)
+    big = x * 255
+    s255 = float(O.ssim(big, big * 0.9))
+    s1 = float(O.ssim(x, x * 0.9))
+    assert abs(s255 - s1) < 1e-4                   # scale-covariant once L follows the data range
+    per = O.ssim(x, x.flip(0), size_average=False)
+    assert per.shape == (2,)
+    from nerf_meets_mlx_amd.ops.metric import gaussian_window
+    np.testing.assert_allclose(gaussian_window(11, 1.5, True), wq.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(gaussian_window(7, 1.5, False), O.ssim_window(7, 1.5, False, torch.float64).numpy(), rtol=1e-12)

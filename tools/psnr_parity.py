@@ -1,19 +1,126 @@
 #!/usr/bin/env python3
-"""PSNR parity at equal iterations: the HIP Trainer (bf16 MFMA) vs the CPU oracle trainer (fp32 autograd
-restatement of entrypoints/__test_nerf.py:200-305) fed the SAME rays, targets and importance uniforms.
+"""PSNR parity at equal iterations: the HIP Trainer (bf16 MFMA) vs the oracle trainer (fp32 autograd restatement of
+entrypoints/__test_nerf.py:200-305) fed the SAME rays, targets and importance uniforms.
 
-    python tools/psnr_parity.py --iters 300 --hw 64 --n-rand 256   (run on the GPU box; a few minutes)
+    python tools/psnr_parity.py --hw 800 --n-rand 1024 --iters 5000 --every 500 --oracle-device cuda   # configs[2]
+    python tools/psnr_parity.py --hw 400 --n-rand 1024 --iters 5000 --every 500 --n-importance 0 --oracle-device cuda   # configs[1]
 
 Prints one JSON line per checkpoint with the PSNR of both on held-out views of the synthetic scene.
-The oracle is the checker here, never the product.
+The oracle is the checker here, never the product.  `--oracle-device cuda` runs the SAME oracle code in fp32 torch ops
+on the ROCm device (it is device-agnostic) only so that a 5000-iteration run takes minutes instead of a day; TF32-like
+shortcuts are switched off for it.  tests/test_gpu_parity.py::test_psnr_parity_training_run calls run() at a reduced size.
 """
-import argparse, json, os, sys, time
+import argparse
+import json
+import os
+import sys
+import time
+
 import numpy as np
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nerf_meets_mlx_amd.dataset import synthetic
-from nerf_meets_mlx_amd.engine.trainer import Trainer
-from oracle import nerf_oracle as O
+from nerf_meets_mlx_amd.dataset import synthetic                      # noqa: E402
+from nerf_meets_mlx_amd.engine.trainer import Trainer                 # noqa: E402
+from nerf_meets_mlx_amd.rendering import ray                          # noqa: E402
+from oracle import nerf_oracle as O                                   # noqa: E402
+
+
+def alive_seed(arch, q, start=0):
+    """The reference feeds raw sigma (no activation, Q9/Q10) into alpha = 1 - exp(-relu(sigma delta)): a network whose
+    initial sigma is negative everywhere has alpha == 0 and an exactly-zero gradient -- it never trains (in the
+    reference too).  A deep ReLU net at init is nearly constant over its inputs, so that is a coin flip per seed; pick
+    the first seed where both nets are alive so that the PSNR comparison is not vacuous."""
+    probe_pos = (torch.rand(64, 8, 3, generator=torch.Generator().manual_seed(0)) - 0.5) * 3.0
+    probe_dir = torch.nn.functional.normalize(torch.randn(64, 3, generator=torch.Generator().manual_seed(1)), dim=-1)
+    for seed in range(start, start + 100):
+        ok = True
+        for sd in (seed, seed + 1):
+            raw = O.run_model(arch, O.init_params(arch, sd), probe_pos, probe_dir, ref_quirks=q)
+            ok = ok and float((raw[..., 3] > 0).float().mean()) > 0.95
+        if ok:
+            return seed
+    raise RuntimeError("no alive seed found")
+
+
+def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_importance=128, seed=-1, quirks=True,
+        lrate_decay=500, oracle_device="cpu", eval_chunk=8192, threads=16, emit=None, dev="cuda"):
+    """Returns the list of checkpoint records; `emit(rec)` is called as they are produced."""
+    torch.set_num_threads(threads)
+    if oracle_device != "cpu":
+        torch.backends.cuda.matmul.allow_tf32 = False                  # plain fp32 GEMMs for the checker
+        try:
+            torch.backends.cuda.matmul.allow_bf16_reduced_precision_reduction = False
+            torch.set_float32_matmul_precision("highest")
+        except Exception:
+            pass
+    H = W = hw
+    imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, views + test_views, seed=0, device=dev)
+    test_imgs, test_poses = imgs[-test_views:], poses[-test_views:]
+    arch = O.NerfArch()
+    if seed < 0:
+        seed = alive_seed(arch, quirks)
+    emit = emit or (lambda rec: None)
+    emit({"seed": seed, "ref_quirks": quirks, "hw": hw, "n_rand": n_rand, "n_importance": n_importance, "views": views,
+          "oracle_device": oracle_device, "iters": iters})
+    tr = Trainer(imgs[:-test_views], poses[:-test_views], K, N_rand=n_rand, n_depth_samples=64, N_importance=n_importance,
+                 seed=seed, device=dev, lrate_decay=lrate_decay, ref_quirks=quirks)
+    ot = O.OracleTrainer(arch, 64, n_importance, seed=seed, lrate_decay=lrate_decay, ref_quirks=quirks, device=oracle_device)
+    assert torch.equal(tr.coarse.params.cpu(), ot.pc.detach().cpu())
+    g = torch.Generator().manual_seed(123)
+    od = torch.device(oracle_device)
+    NI = max(n_importance, 1)
+
+    def eval_rays(pose):
+        idx = torch.arange(H * W, device=dev, dtype=torch.int64)
+        return ray.gen_rays(H, W, K, pose[:3, :4].cpu().numpy(), 2.0, 6.0, idx)
+
+    test_rays = [eval_rays(p) for p in test_poses]
+    u_eval = torch.rand(H * W, NI, generator=torch.Generator().manual_seed(7))
+
+    def oracle_psnr():
+        with torch.no_grad():
+            pc = O.unflatten_params(arch, ot.pc.detach())
+            pf = O.unflatten_params(arch, ot.pf.detach()) if ot.pf is not None else None
+            vals = []
+            for img, rays in zip(test_imgs, test_rays):
+                rays_o = rays.to(od)
+                outs = []
+                for s in range(0, H * W, eval_chunk):
+                    r = rays_o[s:s + eval_chunk]
+                    if n_importance > 0:
+                        o = O.render_rays_eval(arch, pc, pf, r, 64, n_importance, u_eval[s:s + eval_chunk].to(od), True, False, quirks)
+                    else:
+                        o = O.render_rays(arch, pc, r, 64, True, ref_quirks=quirks)
+                    outs.append(o["rgb_map"])
+                rgb = torch.cat(outs, 0)
+                vals.append(float(O.psnr(rgb, img.reshape(-1, 3).to(od))))
+        return float(np.mean(vals))
+
+    def hip_psnr():
+        vals = []
+        for img, rays in zip(test_imgs, test_rays):
+            rgb = tr.render_rays(rays, u=u_eval.to(dev) if n_importance > 0 else None)
+            vals.append(float(10.0 * torch.log10(1.0 / torch.mean((rgb - img.reshape(-1, 3)) ** 2))))
+        return float(np.mean(vals))
+
+    recs = []
+    t0 = time.time()
+    for it in range(1, iters + 1):
+        rays, target = tr.sample_batch()
+        u = torch.rand(n_rand, NI, generator=g)
+        lh = tr.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
+        lo = ot.step(rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od), u.to(od))
+        if it % every == 0 or it == iters:
+            rec = {"iter": it, "psnr_hip": hip_psnr(), "psnr_oracle": oracle_psnr(),
+                   "loss_coarse_hip": float(lh["loss_coarse"]), "loss_coarse_oracle": lo["loss_coarse"],
+                   "elapsed_s": time.time() - t0}
+            if n_importance > 0:
+                rec["loss_fine_hip"], rec["loss_fine_oracle"] = float(lh["loss_fine"]), lo["loss_fine"]
+            rec["delta_db"] = rec["psnr_hip"] - rec["psnr_oracle"]
+            recs.append(rec)
+            emit(rec)
+    return recs
 
 
 def main():
@@ -22,66 +129,20 @@ def main():
     ap.add_argument("--hw", type=int, default=64)
     ap.add_argument("--n-rand", type=int, default=256)
     ap.add_argument("--views", type=int, default=12)
+    ap.add_argument("--test-views", type=int, default=2)
+    ap.add_argument("--n-importance", type=int, default=128)
     ap.add_argument("--every", type=int, default=100)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--lrate-decay", type=int, default=500)
+    ap.add_argument("--eval-chunk", type=int, default=8192)
+    ap.add_argument("--oracle-device", default="cpu", help="cpu | cuda: where the fp32 oracle trainer runs")
     ap.add_argument("--seed", type=int, default=-1, help="-1: first seed whose coarse AND fine nets start with sigma > 0")
     ap.add_argument("--no-quirks", action="store_true")
     a = ap.parse_args()
-    torch.set_num_threads(a.threads)
-    dev = "cuda"
-    H = W = a.hw
-    imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, a.views + 2, seed=0, device=dev)
-    test_imgs, test_poses = imgs[-2:].cpu(), poses[-2:]
-    arch = O.NerfArch()
-    q = not a.no_quirks
-    seed = a.seed
-    if seed < 0:
-        # The reference feeds raw sigma (no activation, Q9/Q10) into alpha = 1 - exp(-relu(sigma delta)): a network whose
-        # initial sigma is negative everywhere has alpha == 0 and an exactly-zero gradient -- it never trains (in the
-        # reference too).  A deep ReLU net at init is nearly constant over its inputs, so that is a coin flip per seed;
-        # pick the first seed where both nets are alive so that the PSNR comparison is not vacuous.
-        probe_pos = (torch.rand(64, 8, 3, generator=torch.Generator().manual_seed(0)) - 0.5) * 3.0
-        probe_dir = torch.nn.functional.normalize(torch.randn(64, 3, generator=torch.Generator().manual_seed(1)), dim=-1)
-        for seed in range(100):
-            ok = True
-            for sd in (seed, seed + 1):
-                raw = O.run_model(arch, O.init_params(arch, sd), probe_pos, probe_dir, ref_quirks=q)
-                ok = ok and float((raw[..., 3] > 0).float().mean()) > 0.95
-            if ok:
-                break
-    print(json.dumps({"seed": seed, "ref_quirks": q}), flush=True)
-    tr = Trainer(imgs[:-2], poses[:-2], K, N_rand=a.n_rand, n_depth_samples=64, N_importance=128, seed=seed, device=dev,
-                 lrate_decay=a.lrate_decay, ref_quirks=q)
-    ot = O.OracleTrainer(arch, 64, 128, seed=seed, lrate_decay=a.lrate_decay, ref_quirks=q)
-    assert torch.equal(tr.coarse.params.cpu(), ot.pc.detach())
-    g = torch.Generator().manual_seed(123)
-
-    def oracle_psnr():
-        with torch.no_grad():
-            pc = O.unflatten_params(arch, ot.pc.detach()); pf = O.unflatten_params(arch, ot.pf.detach())
-            vals = []
-            for img, pose in zip(test_imgs, test_poses):
-                u = torch.rand(H * W, 128, generator=torch.Generator().manual_seed(7))
-                rgb = O.render(arch, pc, pf, H, W, K, pose[:3, :4], 2.0, 6.0, 64, 128, u, chunk=4096, white_bkgd=True, ref_quirks=q)[0]
-                vals.append(float(O.psnr(rgb, img)))
-        return float(np.mean(vals))
-
-    def hip_psnr():
-        return float(np.mean([tr.psnr(p[:3, :4].numpy(), im) for im, p in zip(test_imgs, test_poses)]))
-
-    t0 = time.time()
-    for it in range(1, a.iters + 1):
-        rays, target = tr.sample_batch()
-        u = torch.rand(a.n_rand, 128, generator=g)
-        lh = tr.train_step(rays, target, u.to(dev))
-        lo = ot.step(rays[:, 0:3].cpu(), rays[:, 3:6].cpu(), target.cpu(), u)
-        if it % a.every == 0 or it == a.iters:
-            rec = {"iter": it, "psnr_hip": hip_psnr(), "psnr_oracle": oracle_psnr(),
-                   "loss_coarse_hip": float(lh["loss_coarse"]), "loss_coarse_oracle": lo["loss_coarse"],
-                   "loss_fine_hip": float(lh["loss_fine"]), "loss_fine_oracle": lo["loss_fine"], "elapsed_s": time.time() - t0}
-            rec["delta_db"] = rec["psnr_hip"] - rec["psnr_oracle"]
-            print(json.dumps(rec), flush=True)
+    run(hw=a.hw, n_rand=a.n_rand, iters=a.iters, every=a.every, views=a.views, test_views=a.test_views,
+        n_importance=a.n_importance, seed=a.seed, quirks=not a.no_quirks, lrate_decay=a.lrate_decay,
+        oracle_device=a.oracle_device, eval_chunk=a.eval_chunk, threads=a.threads,
+        emit=lambda rec: print(json.dumps(rec), flush=True))
 
 
 if __name__ == "__main__":
