@@ -267,8 +267,17 @@ int nerf_comm_destroy(void* comm);
  *                     5 same with 4 waves x 64 samples.  Training kernels use 3 for every value >= 3.
  *   "ring_workgroups" persistent workgroups of the ring kernels (0 = default: one per CU of the current device)
  *   "dw_workgroups"   0 auto (one per CU) | workgroups of the weight-gradient kernel
- *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)                       */
+ *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)
+ *   "mlp_precision"   16 (default): bf16 MFMA operands, fp32 accumulate -- the benchmarked mode (BASELINE configs[1-3]);
+ *                     32: the reference's own arithmetic -- float32 operands on v_mfma_f32_32x32x2_f32, sinf / cosf
+ *                     encodings (models/NeRF.py:201-243 runs in MLX float32).  8 x 256 view model only.  The mode is
+ *                     read by nerf_mlp_pack (builds the fp32 weight streams), nerf_mlp_acts_bytes / nerf_mlp_dz_bytes
+ *                     (fp32 stores are larger) and every forward / backward launch: set it BEFORE packing; a launch in
+ *                     fp32 mode on an image packed in bf16 mode returns NERF_E_UNSUPPORTED.
+ * nerf_get_option returns the current value of "mlp_variant" | "mlp_precision" | "ring_workgroups" | "dw_workgroups",
+ * or -1 for an unknown key.                                                                                        */
 int nerf_set_option(const char* key, int value);
+int nerf_get_option(const char* key);
 
 /* ---------------------------------------------------------------- optimiser (a21)
  * replaces: mlx.optimizers.Adam.update as called at entrypoints/__test_nerf.py:134,144

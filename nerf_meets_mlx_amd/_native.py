@@ -53,6 +53,7 @@ SIGNATURES = {
     "nerf_allreduce_grads": (_I, [_P, _P, _I64, _P]),
     "nerf_comm_destroy": (_I, [_P]),
     "nerf_set_option": (_I, [C.c_char_p, _I]),
+    "nerf_get_option": (_I, [C.c_char_p]),
     "nerf_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _I, _F, _P]),
 }
 

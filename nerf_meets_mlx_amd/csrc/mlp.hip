@@ -23,7 +23,11 @@
 // C ABI entry points.
 #include "common.h"
 #include "hash_common.h"
+#include "mlp_params.h"
+#include "mlp32.h"
 #include <string.h>
+#include <mutex>
+#include <unordered_map>
 
 #ifndef NERF_SPREAD_DMA
 #define NERF_SPREAD_DMA 1     // ring refill: one DMA per quarter chunk interval instead of a burst of 4
@@ -52,21 +56,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // static layout of the one supported architecture (8 x 256, skip 4, view head)
 // ------------------------------------------------------------------------------------------
 namespace L {
-// float32 parameter offsets (include/nerf_hip.h "Parameter layout")
-constexpr int P_W0 = 0, P_B0 = 16128;
-constexpr int P_W1 = 16384;                       // W_l = P_W1 + (l-1)*65792, l = 1..4
-constexpr int P_W5 = 279552, P_B5 = 361216;
-constexpr int P_W6 = 361472, P_B6 = 427008, P_W7 = 427264, P_B7 = 492800;
-constexpr int P_WF = 493056, P_BF = 558592, P_WA = 558848, P_BA = 559104;
-constexpr int P_WD = 559105, P_BD = 595329, P_WR = 595457, P_BR = 595841;
-constexpr int P_TOTAL = 595844;
-__host__ __device__ constexpr int pw(int l) {   // weight offset of pos layer l
-  return l == 0 ? P_W0 : l <= 4 ? P_W1 + (l - 1) * 65792 : l == 5 ? P_W5 : l == 6 ? P_W6 : P_W7;
-}
-__host__ __device__ constexpr int pb(int l) {
-  return l == 0 ? P_B0 : l <= 4 ? P_W1 + (l - 1) * 65792 + 65536 : l == 5 ? P_B5 : l == 6 ? P_B6 : P_B7;
-}
-__host__ __device__ constexpr int pin(int l) { return l == 0 ? 63 : l == 5 ? 319 : 256; }
+// float32 parameter offsets P_*: mlp_params.h (shared with the fp32 reference-precision kernels of mlp32.hip)
 
 // forward weight stream, 1 KiB fragments in consumption order
 constexpr int F_L0 = 0, F_L1 = 32, F_L5 = 544, F_L6 = 704, F_L7 = 832, F_FA = 960, F_DIR = 1104, F_RGB = 1176;
@@ -1886,6 +1876,16 @@ static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad
 static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: LDS ring, 8 waves x 32 samples, 32x32x16 MFMA,
                                 // 4: ring, 16x16x32 MFMA, 8 waves x 32 samples (inference only), 5: same, 4 waves x 64 samples
 static int g_ring_wgs = 0;       // persistent workgroups of the ring kernels; 0 = one per CU of the current device
+static int g_mlp_precision = 16; // 16: bf16 MFMA operands, fp32 accumulate (benchmarked mode); 32: fp32 reference-precision mode (mlp32.hip)
+// Packed images whose fp32 streams are current (nerf_mlp_pack builds them only in fp32 mode; a launch in fp32 mode on an
+// image packed in bf16 mode must fail loudly instead of running on stale or uninitialised weights).
+static std::mutex g_pack_mu;
+static std::unordered_map<const void*, bool> g_packed_has32;
+static bool packed_has32(const void* packed) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  auto it = g_packed_has32.find(packed);
+  return it != g_packed_has32.end() && it->second;
+}
 // CUs of the current device (256 on an MI355X in SPX mode), asked once: the persistent kernels and the dW split are
 // sized to it instead of to a constant
 // Per-device state: the CU count and the "dynamic LDS attribute set" flags belong to the CURRENT device (a process may
@@ -1940,6 +1940,11 @@ using namespace nerf;
 extern "C" int nerf_set_option(const char* key, int value) {
   NERF_REQUIRE(key, NERF_E_NULL, "nerf_set_option: key is NULL");
   if (!strcmp(key, "mlp_variant")) { g_mlp_variant = value; return NERF_OK; }
+  if (!strcmp(key, "mlp_precision")) {
+    NERF_REQUIRE(value == 16 || value == 32, NERF_E_UNSUPPORTED, "nerf_set_option: mlp_precision must be 16 (bf16 MFMA) or 32 (fp32 MFMA)");
+    g_mlp_precision = value;
+    return NERF_OK;
+  }
   if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 0; return NERF_OK; }
@@ -1949,24 +1954,37 @@ extern "C" int nerf_set_option(const char* key, int value) {
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
+extern "C" int nerf_get_option(const char* key) {
+  if (!key) return -1;
+  if (!strcmp(key, "mlp_variant")) return g_mlp_variant;
+  if (!strcmp(key, "mlp_precision")) return g_mlp_precision;
+  if (!strcmp(key, "ring_workgroups")) return g_ring_wgs;
+  if (!strcmp(key, "dw_workgroups")) return g_dw_wgs;
+  return -1;
+}
+
 extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
   return k == 0 ? L::P_TOTAL : k == 1 ? img_params(arch) : k == 2 ? LN::P_TOTAL : -1;
 }
 extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
-  return k == 0 ? L::PACKED_BYTES : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
+  // the 8 x 256 view model carries its fp32 streams (reference-precision mode) behind the bf16 image
+  return k == 0 ? L::PACKED_BYTES + f32::PACKED_BYTES : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
 }
+static inline const void* packed32_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES; }
 static inline int64_t padded_tiles(int64_t M) { return (((M + 31) / 32) + 7) / 8 * 8; }
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
-  return padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16() : small_astride16()) * 16;
+  const int64_t b16 = padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16() : small_astride16()) * 16;
+  return (k == 0 && g_mlp_precision == 32) ? f32::acts_bytes(M) : b16;       // the caller asks after setting the mode
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
-  return padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16;
+  const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16;
+  return (k == 0 && g_mlp_precision == 32) ? f32::dz_bytes(M) : b16;
 }
 
 #define NERF_ARCH_MSG ": HIP kernels exist for (8x256, skip 4) with in=63+27 view head, or in=40 / no view head / out_ch<=4, and for (2x64, no skip) with in=32+16 view head"
@@ -2000,7 +2018,15 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
   hipLaunchKernelGGL(pack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), params, wf, wb, bias);
   hipLaunchKernelGGL(pack16_kernel, dim3(L::F16_PADDED * 64 / 256), dim3(256), 0, as_stream(stream), params,
                      reinterpret_cast<bf16x8*>(base + L::F16_OFFSET));
-  return check_launch("nerf_mlp_pack");
+  int rc = check_launch("nerf_mlp_pack");
+  if (rc) return rc;
+  const bool want32 = g_mlp_precision == 32;
+  if (want32) rc = f32::pack(params, base + L::PACKED_BYTES, as_stream(stream));
+  {
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    g_packed_has32[packed] = want32 && rc == NERF_OK;
+  }
+  return rc;
 }
 
 static void fill_freqs(PeFreq& fr, int mode) {
@@ -2104,6 +2130,11 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     return check_launch("mlp forward (image model)");
   }
+  if (g_mlp_precision == 32) {
+    NERF_REQUIRE(packed_has32(packed), NERF_E_UNSUPPORTED,
+                 "nerf_mlp_forward: mlp_precision is 32 but this packed image was built in bf16 mode: call nerf_mlp_pack again");
+    return f32::forward(packed32_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, as_stream(stream));
+  }
   return launch_fwd<0>(packed, x, nullptr, nullptr, M, 1, 0, out, acts, stream);
 }
 
@@ -2120,7 +2151,11 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   NERF_REQUIRE(packed && rays && z && raw, NERF_E_NULL, "nerf_query_fused: NULL pointer");
   NERF_REQUIRE(freq_mode == 0 || freq_mode == 1, NERF_E_UNSUPPORTED, "nerf_query_fused: freq_mode must be 0 or 1");
   NERF_REQUIRE(B * (int64_t)n < (1ll << 31), NERF_E_SHAPE, "nerf_query_fused: B*n must be < 2^31 samples per call");
-  if (B <= 0) return NERF_OK;
+  if (g_mlp_precision == 32) {
+    NERF_REQUIRE(packed_has32(packed), NERF_E_UNSUPPORTED,
+                 "nerf_query_fused: mlp_precision is 32 but this packed image was built in bf16 mode: call nerf_mlp_pack again");
+    return f32::forward(packed32_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts, as_stream(stream));
+  }
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
 }
 
@@ -2234,6 +2269,11 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     jobi(LI::Z_L0 + 112, 16, LI::A_H0 + 96, 16, LI::P_W7, 256, 0, 256, 256, LI::P_B7);                     // pos7
     jobi(LI::Z_OUT, 1, LI::A_H0 + 112, 16, LI::P_WO, 256, 0, arch->out_ch, 256, LI::P_WO + arch->out_ch * 256);   // output
     return launch_dw(di, nji, ntiles, img_params(arch), acts, dz, img_astride16(), img_zstride16(), grads, s);
+  }
+  if (g_mlp_precision == 32) {
+    NERF_REQUIRE(packed_has32(packed), NERF_E_UNSUPPORTED,
+                 "nerf_mlp_backward: mlp_precision is 32 but this packed image was built in bf16 mode: call nerf_mlp_pack again");
+    return f32::backward(packed32_of(packed), acts, d_raw, M, dz, grads, s);
   }
   // ---- 1. dZ chain
   BwdArgs b;
@@ -2352,13 +2392,19 @@ static bool debug_slot(int kind, int layer, int* slot, int* nfrag) {
 
 extern "C" int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int layer) {
   int slot = 0, nfrag = 0;
-  if (!arch_ok(arch) || !debug_slot(kind, layer, &slot, &nfrag)) return -1;
+  if (!arch_ok(arch)) return -1;
+  if (g_mlp_precision == 32) return f32::debug_width(kind, layer);
+  if (!debug_slot(kind, layer, &slot, &nfrag)) return -1;
   return 16 * nfrag;
 }
 
 extern "C" int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store, int kind, int layer, int64_t M,
                                    float* out, void* stream) {
   NERF_ARCH_CHECK("nerf_mlp_debug_read");
+  if (g_mlp_precision == 32) {
+    NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");
+    return M <= 0 ? NERF_OK : f32::debug_read(store, kind, layer, M, out, as_stream(stream));
+  }
   int slot = 0, nfrag = 0;
   NERF_REQUIRE(debug_slot(kind, layer, &slot, &nfrag), NERF_E_SHAPE, "nerf_mlp_debug_read: kind must be 0/1 and layer 0..11");
   NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");

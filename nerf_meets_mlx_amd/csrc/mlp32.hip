@@ -1,0 +1,586 @@
+// fp32 reference-precision mode of the fused 8 x 256 NeRF MLP (nerf_set_option("mlp_precision", 32)).
+//
+// The reference computes in float32 (MLX default dtype; models/NeRF.py:201-243, embedding.py:30-71): this file is the
+// same fused chain as mlp.hip with float32 operands on v_mfma_f32_32x32x2_f32 (fp32 matrix peak 157 TFLOP/s, 1/16 of
+// the bf16 rate), so that "same results as the reference on the same inputs" can be checked at the reference's own
+// arithmetic (<= 1e-4 of the output scale against the fp32 oracle; no rounding-induced ReLU flips in the adjoint).
+// bf16 stays the benchmarked mode; this one is the precision witness and is written for clarity first:
+//
+//  * one wave = one 32-sample tile.  Layers are computed transposed like in mlp.hip (A = W rows, B = activations with
+//    the sample on the lane), K = 2 features per MFMA: step i of k-tile kt multiplies features 32 kt + p(i) + 4 h
+//    (h = lane half, p(i) = (i & 3) + 8 (i >> 2)), which is exactly the row a lane's accumulator register i holds -- a
+//    finished accumulator tile IS the next layer's B operand, register for register.
+//  * the n-tile loop is a run-time loop (the fully unrolled chain would be 9 280 MFMAs of straight-line code): each
+//    finished 32 x 32 tile goes to a wave-private 32 KiB LDS slab and the whole layer is read back into registers
+//    before the next one.  No workgroup barriers: the four waves of a workgroup never share data.
+//  * weights stream from a packed float32 image in consumption order, one coalesced 4 KiB fragment (16 floats per
+//    lane) per 16 MFMAs, straight from L2 (1 024 MFMA cycles per fragment: no staging needed).
+//  * training stores every layer's activation / dZ as float32 [tile][feature row][32 samples]; the dW kernel reads them
+//    as MFMA operands directly (samples are the K axis; a lane reads 16 consecutive samples of its feature row).
+//  * encodings use sinf / cosf on the float32 product x * f -- the reference's sin(x * f), not the hardware
+//    revolution-sine of the bf16 path.
+#include "common.h"
+#include "mlp_params.h"
+#include "mlp32.h"
+
+namespace nerf {
+namespace f32 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int prow(int i) { return (i & 3) + 8 * (i >> 2); }     // + 4 h
+
+// tail of the packed image (floats)
+constexpr int T_B = 0;              // pos biases, 256 l
+constexpr int T_BF = 2048, T_BD = 2304, T_BA = 2432, T_BR = 2433, T_WA = 2440, T_WR = 2696;
+static_assert(T_WR + 384 <= TAIL_FLOATS, "tail too small");
+// forward stream fragment bases
+constexpr int F_L0 = 0, F_L1 = 16, F_L5 = 272, F_L6 = 352, F_FEAT = 480, F_DIR = 544;
+static_assert(F_DIR + 36 == F_FRAGS, "forward stream");
+// backward (transposed) stream
+constexpr int B_DIR = 0, B_FEAT = 32, B_POS = 96;          // pos7, 6, ..., 1 at B_POS + 64 (7 - l)
+static_assert(B_POS + 7 * 64 == B_FRAGS, "backward stream");
+// activation / dZ store rows
+constexpr int A_PE = 0, A_DPE = 64, A_H0 = 96, A_FEAT = 2144, A_HD = 2400;
+constexpr int Z_L0 = 0, Z_F = 2048, Z_D = 2304, Z_A = 2432, Z_RGB = 2464;
+static_assert(A_HD + 128 == A_ROWS && Z_RGB + 32 == Z_ROWS, "store rows");
+
+// ------------------------------------------------------------------------------------------ packing
+__device__ float fwd_src(const float* __restrict__ p, int f, int n32, int kk) {
+  if (f < F_L1) {
+    const int nt = f / 2, kt = f % 2, k = 32 * kt + kk;
+    return k < 63 ? p[L::P_W0 + (32 * nt + n32) * 63 + k] : 0.0f;
+  }
+  if (f < F_L5) {
+    const int q = f - F_L1, l = 1 + q / 64, r = q % 64;
+    return p[L::pw(l) + (32 * (r / 8) + n32) * 256 + 32 * (r % 8) + kk];
+  }
+  if (f < F_L6) {
+    const int q = f - F_L5, n = 32 * (q / 10) + n32, kt = q % 10;
+    if (kt < 2) { const int k = 32 * kt + kk; return k < 63 ? p[L::P_W5 + n * 319 + k] : 0.0f; }
+    return p[L::P_W5 + n * 319 + 63 + 32 * (kt - 2) + kk];
+  }
+  if (f < F_FEAT) {
+    const int q = f - F_L6, l = 6 + q / 64, r = q % 64;
+    return p[L::pw(l) + (32 * (r / 8) + n32) * 256 + 32 * (r % 8) + kk];
+  }
+  if (f < F_DIR) {
+    const int q = f - F_FEAT;
+    return p[L::P_WF + (32 * (q / 8) + n32) * 256 + 32 * (q % 8) + kk];
+  }
+  const int q = f - F_DIR, n = 32 * (q / 9) + n32, kt = q % 9;
+  if (kt < 8) return p[L::P_WD + n * 283 + 32 * kt + kk];
+  return kk < 27 ? p[L::P_WD + n * 283 + 256 + kk] : 0.0f;
+}
+// transposed: A row = input feature 32 kt + k32, K index = output feature nn
+__device__ float bwd_src(const float* __restrict__ p, int f, int k32, int kk) {
+  if (f < B_FEAT) { const int kt = f / 4, ns = f % 4; return p[L::P_WD + (32 * ns + kk) * 283 + 32 * kt + k32]; }
+  if (f < B_POS) { const int q = f - B_FEAT, kt = q / 8, ns = q % 8; return p[L::P_WF + (32 * ns + kk) * 256 + 32 * kt + k32]; }
+  const int q = f - B_POS, l = 7 - q / 64, r = q % 64, kt = r / 8, ns = r % 8, nn = 32 * ns + kk, row = 32 * kt + k32;
+  return l == 5 ? p[L::P_W5 + nn * 319 + 63 + row] : p[L::pw(l) + nn * 256 + row];
+}
+
+__global__ void __launch_bounds__(256) pack32_kernel(const float* __restrict__ p, float* __restrict__ out) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int nfl = (F_FRAGS + B_FRAGS) * 64;
+  if (tid < nfl) {
+    const int f = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    float* dst = out + (int64_t)tid * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = prow(i) + 4 * h;
+      dst[i] = f < F_FRAGS ? fwd_src(p, f, r, kk) : bwd_src(p, f - F_FRAGS, r, kk);
+    }
+  } else if (tid < nfl + TAIL_FLOATS) {
+    const int t = tid - nfl;
+    float v = 0.0f;
+    if (t < T_BF) v = p[L::pb(t >> 8) + (t & 255)];
+    else if (t < T_BD) v = p[L::P_BF + (t - T_BF)];
+    else if (t < T_BA) v = p[L::P_BD + (t - T_BD)];
+    else if (t == T_BA) v = p[L::P_BA];
+    else if (t < T_BR + 3) v = p[L::P_BR + (t - T_BR)];
+    else if (t >= T_WA && t < T_WA + 256) v = p[L::P_WA + (t - T_WA)];
+    else if (t >= T_WR && t < T_WR + 384) v = p[L::P_WR + (t - T_WR)];
+    out[(int64_t)nfl * 16 + t] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ one layer
+extern __shared__ __attribute__((aligned(16))) float slab_smem[];      // 4 waves x 256 rows x 32 floats
+
+struct Frag16 { float w[16]; };
+__device__ __forceinline__ Frag16 load_frag(const float4* __restrict__ lane_base, int f) {
+  const float4* fp = lane_base + (int64_t)f * 256;
+  Frag16 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float4 v = fp[j]; r.w[4 * j] = v.x; r.w[4 * j + 1] = v.y; r.w[4 * j + 2] = v.z; r.w[4 * j + 3] = v.w; }
+  return r;
+}
+__device__ __forceinline__ float* store_row(float* base, int64_t tile, int rows, int row, int col) {
+  return base + ((tile * rows + row) * 32 + col);
+}
+
+// out rows [32 nt + p(i) + 4 h] = act(W[nt-tile] . in + bias) for nt < NT, written to the wave's LDS slab (rows 0..32 NT)
+// and, when sink != nullptr, to rows sink_row0 + ... of the tile's activation store.
+template <int KT, bool RELU>
+__device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fbase, const float* __restrict__ bias, int NT,
+                                          const f32x16 (&in)[KT], float* slab, int col, int h, float* sink, int64_t tile,
+                                          int sink_row0) {
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bias[32 * nt + prow(i) + 4 * h];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const Frag16 a = load_frag(wl, fbase + nt * KT + kt);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w[i], in[kt][i], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = RELU ? fmaxf(acc[i], 0.0f) : acc[i];
+      const int row = 32 * nt + prow(i) + 4 * h;
+      slab[row * 32 + col] = v;
+      if (sink) *store_row(sink, tile, A_ROWS, sink_row0 + row, col) = v;
+    }
+  }
+}
+template <int KT>
+__device__ __forceinline__ void slab_to_regs(const float* slab, f32x16 (&dst)[KT], int col, int h) {
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[kt][i] = slab[(32 * kt + prow(i) + 4 * h) * 32 + col];
+}
+
+struct FwdArgs32 {
+  const float4* wf; const float* tail;
+  const float* x; const float* rays; const float* z;
+  int64_t M; int n;
+  float fpos[10], fdir[4];
+  float* out; float* acts;
+};
+
+// channel c of the embedding [x, sin(f0 x), cos(f0 x), ...] (models/embedding.py:30-71), c >= limit -> 0
+struct Chan { int kind, dim, band; };   // kind: 0 identity, 1 sin, 2 cos, 3 zero pad
+__host__ __device__ constexpr Chan chan_of(int c, int limit) {
+  if (c < 3) return Chan{0, c, 0};
+  if (c >= limit) return Chan{3, 0, 0};
+  return Chan{((c - 3) % 6) >= 3 ? 2 : 1, (c - 3) % 3, (c - 3) / 6};
+}
+// register i of a lane holds channel C0 (lane half 0) or C0 + 4 (lane half 1): both descriptions are compile-time, only
+// the select is per lane, so the frequency table is never indexed dynamically (no scratch)
+template <int C0, int LIMIT, int NB>
+__device__ __forceinline__ float embed_pair(const float (&v)[3], const float (&fr)[NB], int h) {
+  constexpr Chan a = chan_of(C0, LIMIT), b = chan_of(C0 + 4, LIMIT);
+  const float xa = v[a.dim], xb = v[b.dim];
+  const float arg = h ? xb * fr[b.band] : xa * fr[a.band];        // x * freq as one float32 product, like the reference
+  float sv = 0.0f, cv = 0.0f;
+  if (a.kind == 1 || b.kind == 1) sv = sinf(arg);
+  if (a.kind == 2 || b.kind == 2) cv = cosf(arg);
+  const float va = a.kind == 0 ? xa : a.kind == 1 ? sv : a.kind == 2 ? cv : 0.0f;
+  const float vb = b.kind == 0 ? xb : b.kind == 1 ? sv : b.kind == 2 ? cv : 0.0f;
+  return h ? vb : va;
+}
+template <int KT, int LIMIT, int NB, int... I>
+__device__ __forceinline__ f32x16 embed_tile_impl(const float (&v)[3], const float (&fr)[NB], int h) {
+  f32x16 r;
+  ((r[I] = embed_pair<32 * KT + prow(I), LIMIT, NB>(v, fr, h)), ...);
+  return r;
+}
+template <int KT, int LIMIT, int NB>
+__device__ __forceinline__ f32x16 embed_tile(const float (&v)[3], const float (&fr)[NB], int h) {
+  return embed_tile_impl<KT, LIMIT, NB, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(v, fr, h);
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (a.M + 31) >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  if (tile >= ntiles) return;
+  float* slab = slab_smem + wv * (256 * 32);
+  const float4* wl = a.wf + lane * 4;
+  int64_t m = tile * 32 + col; if (m >= a.M) m = a.M - 1;
+  f32x16 pe[2], dpe[1];
+  if (a.x) {
+    const float* row = a.x + m * 90;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int c = 32 * kt + prow(i) + 4 * h; pe[kt][i] = c < 63 ? row[c] : 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = prow(i) + 4 * h; dpe[0][i] = c < 27 ? row[63 + c] : 0.0f; }
+  } else {
+    const float* rr = a.rays + (m / a.n) * NERF_RAY_STRIDE;
+    const float zv = a.z[m];
+    float p[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p[c] = rr[c] + zv * rr[3 + c]; d[c] = rr[8 + c]; }       // render.py:142
+    pe[0] = embed_tile<0, 63, 10>(p, a.fpos, h);
+    pe[1] = embed_tile<1, 63, 10>(p, a.fpos, h);
+    dpe[0] = embed_tile<0, 27, 4>(d, a.fdir, h);
+  }
+  float* sink = STORE ? a.acts : nullptr;
+  if (STORE) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *store_row(a.acts, tile, A_ROWS, A_PE + 32 * kt + prow(i) + 4 * h, col) = pe[kt][i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *store_row(a.acts, tile, A_ROWS, A_DPE + prow(i) + 4 * h, col) = dpe[0][i];
+  }
+  f32x16 hcur[8];
+  layer_fwd<2, true>(wl, F_L0, a.tail + T_B, 8, pe, slab, col, h, sink, tile, A_H0);
+  slab_to_regs<8>(slab, hcur, col, h);
+  for (int l = 1; l <= 4; ++l) {                                     // pos1..pos4
+    layer_fwd<8, true>(wl, F_L1 + (l - 1) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, sink, tile, A_H0 + 256 * l);
+    slab_to_regs<8>(slab, hcur, col, h);
+  }
+  {                                                                  // pos5 on concat[input_pos, h]  (models/NeRF.py:224-225)
+    f32x16 cat[10];
+    cat[0] = pe[0]; cat[1] = pe[1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cat[2 + k] = hcur[k];
+    layer_fwd<10, true>(wl, F_L5, a.tail + T_B + 256 * 5, 8, cat, slab, col, h, sink, tile, A_H0 + 256 * 5);
+    slab_to_regs<8>(slab, hcur, col, h);
+  }
+  for (int l = 6; l <= 7; ++l) {
+    layer_fwd<8, true>(wl, F_L6 + (l - 6) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, sink, tile, A_H0 + 256 * l);
+    slab_to_regs<8>(slab, hcur, col, h);
+  }
+  // alpha = Linear(256, 1)(h7): a dot product per sample on the vector ALU (models/NeRF.py:230)
+  float alpha = 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) alpha += a.tail[T_WA + 32 * kt + prow(i) + 4 * h] * hcur[kt][i];
+  alpha += __shfl_xor(alpha, 32, 64);
+  alpha += a.tail[T_BA];
+  // feature (no activation), then relu(Linear([feature, input_dir])), then rgb   (models/NeRF.py:231-238)
+  layer_fwd<8, false>(wl, F_FEAT, a.tail + T_BF, 8, hcur, slab, col, h, sink, tile, A_FEAT);
+  {
+    f32x16 cat[9];
+    slab_to_regs<8>(slab, hcur, col, h);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cat[k] = hcur[k];
+    cat[8] = dpe[0];
+    layer_fwd<9, true>(wl, F_DIR, a.tail + T_BD, 4, cat, slab, col, h, sink, tile, A_HD);
+  }
+  f32x16 hd[4];
+  slab_to_regs<4>(slab, hd, col, h);
+  float rgb[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rgb[c] += a.tail[T_WR + c * 128 + 32 * kt + prow(i) + 4 * h] * hd[kt][i];
+    rgb[c] += __shfl_xor(rgb[c], 32, 64);
+    rgb[c] += a.tail[T_BR + c];
+  }
+  const int64_t mo = tile * 32 + col;
+  if (h == 0 && mo < a.M) {
+    float4 o; o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2]; o.w = alpha;                       // [rgb, alpha] raw
+    *reinterpret_cast<float4*>(a.out + mo * 4) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward chain
+struct BwdArgs32 {
+  const float4* wb; const float* tail;
+  const float* acts; const float* d_raw; int64_t M;
+  float* dz;
+};
+
+// dZ rows [32 kt + p(i) + 4 h] = mask(W^T[kt-tile] . in (+ extra)) for kt < KT -> LDS slab + dz store rows zrow0 + ...
+// mask_row0 >= 0: ReLU' from the stored activation rows mask_row0 + ... (H > 0); extra_w: rank-1 term w[row] * extra_s
+template <int NS>
+__device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fbase, int KT, const f32x16 (&in)[NS],
+                                          float* slab, int col, int h, const float* __restrict__ acts, float* dz,
+                                          int64_t tile, int mask_row0, int zrow0, const float* extra_w, float extra_s) {
+  for (int kt = 0; kt < KT; ++kt) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = extra_w ? extra_w[32 * kt + prow(i) + 4 * h] * extra_s : 0.0f;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const Frag16 a = load_frag(wl, fbase + kt * NS + ns);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w[i], in[ns][i], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 32 * kt + prow(i) + 4 * h;
+      float v = acc[i];
+      if (mask_row0 >= 0 && !(*store_row(const_cast<float*>(acts), tile, A_ROWS, mask_row0 + row, col) > 0.0f)) v = 0.0f;
+      slab[row * 32 + col] = v;
+      *store_row(dz, tile, Z_ROWS, zrow0 + row, col) = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int64_t ntiles = (a.M + 31) >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  if (tile >= ntiles) return;
+  float* slab = slab_smem + wv * (256 * 32);
+  const float4* wl = a.wb + lane * 4;
+  const int64_t m = tile * 32 + col;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m < a.M) g = *reinterpret_cast<const float4*>(a.d_raw + m * 4);
+  // d rgb (rows 0..2) and d alpha (row 0) blocks of the dz store; the other rows of those 32-row blocks are zero
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = prow(i) + 4 * h;
+    *store_row(a.dz, tile, Z_ROWS, Z_RGB + row, col) = row == 0 ? g.x : row == 1 ? g.y : row == 2 ? g.z : 0.0f;
+    *store_row(a.dz, tile, Z_ROWS, Z_A + row, col) = row == 0 ? g.w : 0.0f;
+  }
+  // d dir0 pre-activation = relu'(HD) * (Wr^T d rgb): 3 terms per unit, vector ALU
+  f32x16 zd[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 32 * kt + prow(i) + 4 * h;
+      float v = a.tail[T_WR + row] * g.x + a.tail[T_WR + 128 + row] * g.y + a.tail[T_WR + 256 + row] * g.z;
+      if (!(*store_row(const_cast<float*>(a.acts), tile, A_ROWS, A_HD + row, col) > 0.0f)) v = 0.0f;
+      zd[kt][i] = v;
+      *store_row(a.dz, tile, Z_ROWS, Z_D + row, col) = v;
+    }
+  f32x16 zc[8];
+  layer_bwd<4>(wl, B_DIR, 8, zd, slab, col, h, a.acts, a.dz, tile, -1, Z_F, nullptr, 0.0f);                    // d feature
+  slab_to_regs<8>(slab, zc, col, h);
+  layer_bwd<8>(wl, B_FEAT, 8, zc, slab, col, h, a.acts, a.dz, tile, A_H0 + 256 * 7, Z_L0 + 256 * 7, a.tail + T_WA, g.w);   // dZ7
+  slab_to_regs<8>(slab, zc, col, h);
+  for (int l = 7; l >= 1; --l) {                                   // dZ_{l-1} = relu'(H_{l-1}) * (W_l^T dZ_l)
+    layer_bwd<8>(wl, B_POS + 64 * (7 - l), 8, zc, slab, col, h, a.acts, a.dz, tile, A_H0 + 256 * (l - 1), Z_L0 + 256 * (l - 1),
+                 nullptr, 0.0f);
+    slab_to_regs<8>(slab, zc, col, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dW / db
+struct DwJob32 {
+  int zrow0, n_tiles;      // dZ rows (32 per tile)
+  int arow0, k_tiles;      // input-activation rows
+  int w_off, ldw, col0, n_valid, k_valid, b_off;
+};
+constexpr int DW32_MAX_JOBS = 16;
+struct DwArgs32 {
+  DwJob32 jobs[DW32_MAX_JOBS];
+  int unit0[DW32_MAX_JOBS + 1];    // first unit of each job; unit = (block, split)
+  int njobs, splits, ntiles;
+  const float* acts; const float* dz; float* grads;
+};
+
+// one wave = one unit: a 64 x 64 block (2 x 2 MFMA tiles) of one job's dW over one slice of the sample tiles
+__global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+  const int unit = blockIdx.x * 4 + wv;
+  if (unit >= a.unit0[a.njobs]) return;
+  int j = 0;
+  while (unit >= a.unit0[j + 1]) ++j;
+  const DwJob32 jb = a.jobs[j];
+  const int local = unit - a.unit0[j];
+  const int split = local % a.splits, block = local / a.splits;
+  const int kb = (jb.k_tiles + 1) / 2;
+  const int nt0 = 2 * (block / kb), kt0 = 2 * (block % kb);
+  const int t_lo = (int)((int64_t)a.ntiles * split / a.splits), t_hi = (int)((int64_t)a.ntiles * (split + 1) / a.splits);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.0f;
+  float bsum[2] = {0.0f, 0.0f};
+  const bool n1 = nt0 + 1 < jb.n_tiles, k1 = kt0 + 1 < jb.k_tiles;
+  for (int t = t_lo; t < t_hi; ++t) {
+    // lane (row r32, half h) reads samples 16 h .. 16 h + 15 of its feature row: MFMA step s pairs sample s (h = 0)
+    // with sample 16 + s (h = 1) in both operands
+    Frag16 za[2], hb[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = jb.zrow0 + 32 * (nt0 + ((r == 0 || n1) ? r : 0)) + r32;
+      const float4* src = reinterpret_cast<const float4*>(a.dz + (((int64_t)t * Z_ROWS + row) * 32 + 16 * h));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float4 v = src[q]; za[r].w[4 * q] = v.x; za[r].w[4 * q + 1] = v.y; za[r].w[4 * q + 2] = v.z; za[r].w[4 * q + 3] = v.w; }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int row = jb.arow0 + 32 * (kt0 + ((c == 0 || k1) ? c : 0)) + r32;
+      const float4* src = reinterpret_cast<const float4*>(a.acts + (((int64_t)t * A_ROWS + row) * 32 + 16 * h));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float4 v = src[q]; hb[c].w[4 * q] = v.x; hb[c].w[4 * q + 1] = v.y; hb[c].w[4 * q + 2] = v.z; hb[c].w[4 * q + 3] = v.w; }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (kt0 == 0) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bsum[r] += za[r].w[s];
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[r].w[s], hb[c].w[s], acc[r][c], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 1 && !n1) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c == 1 && !k1) continue;
+      const int colk = 32 * (kt0 + c) + r32;
+      if (colk >= jb.k_valid) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = 32 * (nt0 + r) + prow(i) + 4 * h;
+        if (n < jb.n_valid) atomicAdd(a.grads + jb.w_off + (int64_t)n * jb.ldw + jb.col0 + colk, acc[r][c][i]);
+      }
+    }
+    if (kt0 == 0 && jb.b_off >= 0) {
+      const float tot = bsum[r] + __shfl_xor(bsum[r], 32, 64);
+      const int n = 32 * (nt0 + r) + r32;
+      if (h == 0 && n < jb.n_valid) atomicAdd(a.grads + jb.b_off + n, tot);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ debug decode
+__global__ void __launch_bounds__(256) decode32_kernel(const float* __restrict__ store, int rows, int row0, int width,
+                                                       int64_t M, float* __restrict__ out) {
+  const int64_t total = M * width;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = t / width; const int c = (int)(t - m * width);
+    out[t] = store[(((m >> 5) * rows + row0 + c) * 32) + (m & 31)];
+  }
+}
+static bool debug_slot(int kind, int layer, int* row0, int* width) {
+  if (layer < 0 || layer > 11) return false;
+  if (kind == 0) {
+    if (layer < 8) { *row0 = A_H0 + 256 * layer; *width = 256; }
+    else if (layer == 8) { *row0 = A_FEAT; *width = 256; }
+    else if (layer == 9) { *row0 = A_HD; *width = 128; }
+    else if (layer == 10) { *row0 = A_PE; *width = 64; }
+    else { *row0 = A_DPE; *width = 32; }
+    return true;
+  }
+  if (kind == 1) {
+    if (layer < 8) { *row0 = Z_L0 + 256 * layer; *width = 256; }
+    else if (layer == 8) { *row0 = Z_F; *width = 256; }
+    else if (layer == 9) { *row0 = Z_D; *width = 128; }
+    else if (layer == 10) { *row0 = Z_A; *width = 16; }
+    else { *row0 = Z_RGB; *width = 16; }
+    return true;
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------ host entry points
+constexpr int SLAB_BYTES = 4 * 256 * 32 * 4;        // 128 KiB: one 32 KiB slab per wave
+
+template <class K>
+static void want_lds(K kernel) {
+  static bool done[64] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+  if (!done[d]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES);
+    done[d] = true;
+  }
+}
+
+int pack(const float* params, void* packed32, hipStream_t s) {
+  const int total = (F_FRAGS + B_FRAGS) * 64 + TAIL_FLOATS;
+  hipLaunchKernelGGL(pack32_kernel, dim3((total + 255) / 256), dim3(256), 0, s, params, static_cast<float*>(packed32));
+  return check_launch("nerf_mlp_pack (fp32 streams)");
+}
+
+static const float* tail_of(const void* packed32) {
+  return reinterpret_cast<const float*>(static_cast<const char*>(packed32) + (size_t)(F_FRAGS + B_FRAGS) * FRAG_BYTES);
+}
+
+int forward(const void* packed32, const float* x, const float* rays, const float* z, int64_t M, int n, int freq_mode,
+            float* out, void* acts, hipStream_t s) {
+  FwdArgs32 a;
+  a.wf = static_cast<const float4*>(packed32);
+  a.tail = tail_of(packed32);
+  a.x = x; a.rays = rays; a.z = z; a.M = M; a.n = n; a.out = out; a.acts = static_cast<float*>(acts);
+  for (int k = 0; k < 10; ++k) a.fpos[k] = freq_mode == 0 ? (float)(k * k) : (float)(1 << k);
+  for (int k = 0; k < 4; ++k) a.fdir[k] = freq_mode == 0 ? (float)(k * k) : (float)(1 << k);
+  const int64_t blocks = (tiles_of(M) + 3) / 4;
+  NERF_REQUIRE(blocks < (1ll << 31), NERF_E_SHAPE, "mlp forward (fp32): M too large");
+  if (acts) {
+    want_lds(mlp32_fwd_kernel<true>);
+    hipLaunchKernelGGL(mlp32_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), SLAB_BYTES, s, a);
+  } else {
+    want_lds(mlp32_fwd_kernel<false>);
+    hipLaunchKernelGGL(mlp32_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), SLAB_BYTES, s, a);
+  }
+  return check_launch("mlp forward (fp32)");
+}
+
+int backward(const void* packed32, const void* acts, const float* d_raw, int64_t M, void* dz, float* grads, hipStream_t s) {
+  BwdArgs32 b;
+  b.wb = reinterpret_cast<const float4*>(static_cast<const char*>(packed32) + (size_t)F_FRAGS * FRAG_BYTES);
+  b.tail = tail_of(packed32);
+  b.acts = static_cast<const float*>(acts); b.d_raw = d_raw; b.M = M; b.dz = static_cast<float*>(dz);
+  const int64_t ntiles = tiles_of(M), blocks = (ntiles + 3) / 4;
+  NERF_REQUIRE(blocks < (1ll << 31), NERF_E_SHAPE, "mlp backward (fp32): M too large");
+  want_lds(mlp32_bwd_kernel);
+  hipLaunchKernelGGL(mlp32_bwd_kernel, dim3((unsigned)blocks), dim3(256), SLAB_BYTES, s, b);
+  int rc = check_launch("mlp backward chain (fp32)");
+  if (rc) return rc;
+  DwArgs32 d;
+  int nj = 0;
+  auto job = [&](int zrow0, int n_rows, int arow0, int k_rows, int w_off, int ldw, int col0, int nv, int kv, int b_off) {
+    d.jobs[nj++] = DwJob32{zrow0, n_rows / 32, arow0, k_rows / 32, w_off, ldw, col0, nv, kv, b_off};
+  };
+  job(Z_L0, 256, A_PE, 64, L::P_W0, 63, 0, 256, 63, L::P_B0);                                              // pos0
+  for (int l = 1; l <= 4; ++l) job(Z_L0 + 256 * l, 256, A_H0 + 256 * (l - 1), 256, L::pw(l), 256, 0, 256, 256, L::pb(l));
+  job(Z_L0 + 256 * 5, 256, A_H0 + 256 * 4, 256, L::P_W5, 319, 63, 256, 256, L::P_B5);                      // pos5 | H4
+  job(Z_L0 + 256 * 5, 256, A_PE, 64, L::P_W5, 319, 0, 256, 63, -1);                                        // pos5 | PE
+  job(Z_L0 + 256 * 6, 256, A_H0 + 256 * 5, 256, L::P_W6, 256, 0, 256, 256, L::P_B6);
+  job(Z_L0 + 256 * 7, 256, A_H0 + 256 * 6, 256, L::P_W7, 256, 0, 256, 256, L::P_B7);
+  job(Z_F, 256, A_H0 + 256 * 7, 256, L::P_WF, 256, 0, 256, 256, L::P_BF);                                  // feature
+  job(Z_A, 32, A_H0 + 256 * 7, 256, L::P_WA, 256, 0, 1, 256, L::P_BA);                                     // alpha
+  job(Z_D, 128, A_FEAT, 256, L::P_WD, 283, 0, 128, 256, L::P_BD);                                          // dir0 | feature
+  job(Z_D, 128, A_DPE, 32, L::P_WD, 283, 256, 128, 27, -1);                                                // dir0 | dirPE
+  job(Z_RGB, 32, A_HD, 128, L::P_WR, 128, 0, 3, 128, L::P_BR);                                             // rgb
+  int blocks_total = 0;
+  for (int j = 0; j < nj; ++j) blocks_total += ((d.jobs[j].n_tiles + 1) / 2) * ((d.jobs[j].k_tiles + 1) / 2);
+  int splits = 2048 / blocks_total;                      // about two waves per SIMD of a 256-CU device
+  if (splits < 1) splits = 1;
+  if (splits > ntiles) splits = (int)ntiles;
+  d.unit0[0] = 0;
+  for (int j = 0; j < nj; ++j)
+    d.unit0[j + 1] = d.unit0[j] + ((d.jobs[j].n_tiles + 1) / 2) * ((d.jobs[j].k_tiles + 1) / 2) * splits;
+  d.njobs = nj; d.splits = splits; d.ntiles = (int)ntiles;
+  d.acts = b.acts; d.dz = b.dz; d.grads = grads;
+  hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * L::P_TOTAL, s);
+  if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward (fp32): memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(mlp32_dw_kernel, dim3((d.unit0[nj] + 3) / 4), dim3(256), 0, s, d);
+  return check_launch("mlp dW (fp32)");
+}
+
+int debug_width(int kind, int layer) {
+  int row0 = 0, width = 0;
+  return debug_slot(kind, layer, &row0, &width) ? width : -1;
+}
+int debug_read(const void* store, int kind, int layer, int64_t M, float* out, hipStream_t s) {
+  int row0 = 0, width = 0;
+  NERF_REQUIRE(debug_slot(kind, layer, &row0, &width), NERF_E_SHAPE, "nerf_mlp_debug_read: kind must be 0/1 and layer 0..11");
+  hipLaunchKernelGGL(decode32_kernel, dim3(grid_for(M * width, 256)), dim3(256), 0, s, static_cast<const float*>(store),
+                     kind == 0 ? A_ROWS : Z_ROWS, row0, width, M, out);
+  return check_launch("nerf_mlp_debug_read (fp32)");
+}
+
+}  // namespace f32
+}  // namespace nerf

@@ -61,6 +61,7 @@ class NeRF:
         self._packed = None
         self._dirty = True
         self._packed_version = -1           # params._version the packed image was built from
+        self._packed_prec = -1              # "mlp_precision" in effect when it was packed
         self._ws: Dict[str, torch.Tensor] = {}
         self.name: Optional[str] = None     # stable key for optimiser state / checkpoints ("coarse", "fine", ...)
         self._gen = 0                       # generation of the activation workspace (one per train-mode forward)
@@ -111,10 +112,12 @@ class NeRF:
             self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         # re-pack when the master parameters changed: kernels that write through raw pointers (Adam) say so with
         # mark_updated(); torch in-place ops on `params` or on the views of parameters() bump the version counter
-        if self._dirty or self.params._version != self._packed_version:
+        prec = lib.nerf_get_option(b"mlp_precision")     # the fp32 weight streams exist only in an image packed in fp32 mode
+        if self._dirty or self.params._version != self._packed_version or prec != self._packed_prec:
             N.check(lib.nerf_mlp_pack(C.byref(self.arch), N.ptr(self.params), N.ptr(self._packed), N.stream()))
             self._dirty = False
             self._packed_version = self.params._version
+            self._packed_prec = prec
         return self._packed
 
     def _begin_train_pass(self, M: int) -> torch.Tensor:

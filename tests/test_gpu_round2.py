@@ -75,7 +75,8 @@ def test_mlp_every_layer_and_mask_aligned_backward(B, n):
     (2) the ReLU decisions agree except for units whose pre-activation is ~0 (a last-bit difference in a bf16 input
         moves them across zero): < 0.5 % of the units per layer;
     (3) with the oracle's backward run on the KERNEL's ReLU decisions (masks=...), dW / db agree for EVERY tensor at
-        rel-L2 <= 2e-2 and rel-max <= 8e-2, and every layer's dZ at rel-L2 <= 2e-2.  Without the alignment a
+        rel-L2 <= 5e-3 and rel-max <= 2e-2 (measured: <= 1.1e-3 worst tensor, 5e-4 whole gradient), and every layer's dZ
+        at rel-L2 <= 5e-3 -- four times inside the 2e-2 / 8e-2 the round-1 review asked for.  Without the alignment a
         random-signed upstream gradient makes this comparison measure mask flips, not arithmetic: the oracle's own
         gradient moves by 1.2-4.4 % rel-L2 when its input positions are perturbed by 3e-7 (tests/test_oracle_golden.py::
         test_oracle_gradient_noise_floor), which is why test_mlp_backward_matches_autograd carries a 3e-2 / 6e-2 bar."""
@@ -123,14 +124,14 @@ def test_mlp_every_layer_and_mask_aligned_backward(B, n):
             a, b = grads[off:off + cnt], want[off:off + cnt]
             l2, mx = _rel_l2(a, b), _relmax(a, b)
             worst = max(worst, (l2, (name, part)))
-            assert l2 < 2e-2 and mx < 8e-2, (name, part, l2, mx)
+            assert l2 < 5e-3 and mx < 2e-2, (name, part, l2, mx)
             off += cnt
     assert off == 595844
-    assert _rel_l2(grads, want) < 1e-2, _rel_l2(grads, want)
+    assert _rel_l2(grads, want) < 2e-3, _rel_l2(grads, want)
     for li, name in enumerate(LAYER_NAMES):
         dz = debug_layer(m, "dz", li).cpu()
         ref = taps2[name].grad if name == "feature" else taps2[name].grad * masks[name].float()
-        assert _rel_l2(dz, ref) < 2e-2, (name, _rel_l2(dz, ref))
+        assert _rel_l2(dz, ref) < 5e-3, (name, _rel_l2(dz, ref))
     print(f"[layers B={B} n={n}] worst dW/db rel-L2 {worst[0]:.2e} at {worst[1]}; total {_rel_l2(grads, want):.2e}")
 
 
@@ -300,33 +301,50 @@ def _mini_trainer(kind="nerf", shared=True, seed=4):
 
 
 @pytest.mark.parametrize("kind,shared", [("nerf", True), ("nerf", False), ("ngp", True)])
-def test_checkpoint_npz_roundtrip_continues_bit_identically(tmp_path, kind, shared):
-    """save() mid-training -> load() into a FRESH trainer -> the next iterations are bit-identical to the uninterrupted
-    run: parameters, Adam (m, v) per state key (shared, or coarse / fine, or mlp / tables), step counts (the NGP loop
-    uses bias correction), iteration (LR schedule) and both RNG streams all travel.  The path is given without
-    ".npz" on purpose (np.savez appends it; load() must find it)."""
+def test_checkpoint_npz_roundtrip_continues(tmp_path, kind, shared):
+    """save() mid-training -> load() into a FRESH trainer: the restored state is BIT-identical to the saved one --
+    parameters, Adam (m, v) per state key (shared, or coarse / fine, or mlp / tables), step counts (the NGP loop uses
+    bias correction), iteration (LR schedule) and both RNG streams (the next batch is the same rays, bit for bit) --
+    and training continues on the same trajectory.  The continuation itself is compared at fp32 summation-noise level
+    (losses 1e-5 relative, parameters 1e-6 absolute), not bitwise: the weight-gradient kernel adds split-K partial
+    tiles with float atomics, whose order differs from launch to launch, in one process as much as across a restart.
+    The path is given without ".npz" on purpose (np.savez appends it; load() must find it)."""
     a = _mini_trainer(kind, shared)
     for _ in range(3):
         a.train_step()
     path = a.save(str(tmp_path / "ck"))
     assert path.endswith(".npz") and os.path.exists(path)
-    cont = [a.train_step() for _ in range(2)]
+    snap = {k: m.params.clone() for k, m in a._checkpoint_buffers().items()}
+    snap_adam = {k: [t.clone() for t in v] for k, v in a.opt.state.items()}
     b = _mini_trainer(kind, shared)
     assert b.load(str(tmp_path / "ck")) == 3
-    assert b.it == 3 and set(b.opt.state) == set(a.opt.state)
+    assert b.it == 3 and set(b.opt.state) == set(a.opt.state) and b.opt.step_count == a.opt.step_count
     assert all(v >= 3 for v in b.opt.step_count.values())
+    for k, t in snap.items():
+        assert torch.equal(t, b._checkpoint_buffers()[k].params), k
+    for k, (m_, v_) in snap_adam.items():
+        assert torch.equal(m_, b.opt.state[k][0]) and torch.equal(v_, b.opt.state[k][1]), k
+    ra, ta = a.sample_batch()
+    rb, tb = b.sample_batch()
+    assert torch.equal(ra, rb) and torch.equal(ta, tb)                     # same image, same pixels: RNG streams restored
+    ua = torch.rand(4, device=DEV, generator=a.gen); ub = torch.rand(4, device=DEV, generator=b.gen)
+    assert torch.equal(ua, ub)
+    cont = [a.train_step() for _ in range(2)]
     again = [b.train_step() for _ in range(2)]
     for x, y in zip(cont, again):
         for k in x:
-            assert float(x[k]) == float(y[k]), (k, float(x[k]), float(y[k]))
+            assert abs(float(x[k]) - float(y[k])) <= 1e-5 * abs(float(x[k])), (k, float(x[k]), float(y[k]))
     for k, ma in a._checkpoint_buffers().items():
-        assert torch.equal(ma.params, b._checkpoint_buffers()[k].params), k
-    for k in a.opt.state:
-        assert torch.equal(a.opt.state[k][0], b.opt.state[k][0]) and torch.equal(a.opt.state[k][1], b.opt.state[k][1])
+        diff = (ma.params - b._checkpoint_buffers()[k].params).abs()
+        # Adam without bias correction steps by lr * m / (sqrt(v) + eps): for a weight whose gradient is zero up to
+        # summation noise that ratio is noise of order one, so single weights may differ by a fraction of lr (5e-4);
+        # the bulk agrees to float32 resolution
+        assert float(diff.max()) < 1e-3 and float(diff.mean()) < 1e-6, (k, float(diff.max()), float(diff.mean()))
     # state_dict round trip in memory too
     c = _mini_trainer(kind, shared)
     c.load_state_dict(a.state_dict())
-    assert float(c.train_step()["loss_coarse"]) == float(a.train_step()["loss_coarse"])
+    la, lc = float(a.train_step()["loss_coarse"]), float(c.train_step()["loss_coarse"])
+    assert abs(la - lc) <= 1e-5 * abs(la)
 
 
 def test_entrypoint_checkpoint_flags(tmp_path):
@@ -334,15 +352,17 @@ def test_entrypoint_checkpoint_flags(tmp_path):
     headless entrypoint: periodic .npz checkpoints, automatic resume from the newest one, explicit file, and opt-out."""
     from nerf_meets_mlx_amd.entrypoints import test_nerf
     base = ["--basedir", str(tmp_path), "--expname", "run", "--i_weights", "4"]
-    kw = dict(hw_synthetic=16, n_train_synthetic=3, log_every=1, seed=4)
+    kw = dict(hw_synthetic=40, n_train_synthetic=3, log_every=1, seed=4)      # N_rand = 1024 of 1600 pixels
     full = test_nerf.main(None, max_iter=10, argv=["--basedir", str(tmp_path), "--expname", "full", "--i_weights", "0"], **kw)
     r1 = test_nerf.main(None, max_iter=6, argv=base, **kw)
     assert [os.path.basename(p) for p in r1["checkpoints"]] == ["000004.npz"] and r1["resumed_from"] is None
     r2 = test_nerf.main(None, max_iter=10, argv=base, **kw)                        # resumes at iteration 4
     assert r2["resumed_from"].endswith("000004.npz") and r2["losses"][0][0] == 5
     assert [os.path.basename(p) for p in r2["checkpoints"]] == ["000008.npz"]
-    assert r2["losses"][-1] == full["losses"][-1]                                  # same trajectory as the uninterrupted run
-    assert torch.equal(r2["trainer"].fine.params, full["trainer"].fine.params)
+    for x, y in zip(r2["losses"][-1][1:], full["losses"][-1][1:]):                 # same trajectory as the uninterrupted run
+        assert abs(x - y) <= 1e-4 * abs(y), (r2["losses"][-1], full["losses"][-1])   # (float atomics: not bitwise)
+    dpar = (r2["trainer"].fine.params - full["trainer"].fine.params).abs()
+    assert float(dpar.max()) < 2e-3 and float(dpar.mean()) < 2e-6, (float(dpar.max()), float(dpar.mean()))
     r3 = test_nerf.main(None, max_iter=5, argv=base + ["--no_reload"], **kw)
     assert r3["resumed_from"] is None and r3["losses"][0][0] == 1
     r4 = test_nerf.main(None, max_iter=9, argv=base + ["--no_reload", "--ft_path", r1["checkpoints"][0]], **kw)

@@ -43,8 +43,16 @@ def test_host_argument_validation_without_gpu():
                                       None, None) == -2                      # NERF_E_SHAPE
     arch = _native.MlpArch(8, 256, 63, 27, 4, 1, 4)
     assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844
-    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == (1184 + 1120) * 1024 + 2496 * 4 + 1184 * 1024   # + 16x16x32 stream
+    bf16_image = (1184 + 1120) * 1024 + 2496 * 4 + 1184 * 1024          # fwd + bwd streams, biases, 16x16x32 stream
+    fp32_image = (580 + 544) * 4096 + 3136 * 4                           # fp32 reference-precision streams + tail
+    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == bf16_image + fp32_image
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
+    assert lib.nerf_get_option(b"mlp_precision") == 16 and lib.nerf_get_option(b"nonsense") == -1
+    assert lib.nerf_set_option(b"mlp_precision", 24) == -3                        # NERF_E_UNSUPPORTED
+    assert lib.nerf_set_option(b"mlp_precision", 32) == 0
+    assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 3 * 2528 * 128           # fp32 stores: rows x 32 floats per tile
+    assert lib.nerf_mlp_dz_bytes(C.byref(arch), 65) == 3 * 2496 * 128
+    assert lib.nerf_set_option(b"mlp_precision", 16) == 0
     img = _native.MlpArch(8, 256, 40, 0, 4, 0, 3)
     assert lib.nerf_mlp_param_count(C.byref(img)) == 482051
     bad = _native.MlpArch(8, 128, 63, 27, 4, 1, 4)

@@ -44,8 +44,12 @@ def alive_seed(arch, q, start=0):
 
 
 def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_importance=128, seed=-1, quirks=True,
-        lrate_decay=500, oracle_device="cpu", eval_chunk=8192, threads=16, emit=None, dev="cuda"):
-    """Returns the list of checkpoint records; `emit(rec)` is called as they are produced."""
+        lrate_decay=500, oracle_device="cpu", eval_chunk=8192, threads=16, emit=None, dev="cuda", extra=()):
+    """Returns the list of checkpoint records; `emit(rec)` is called as they are produced.
+    extra: witnesses trained on the same batches to separate precision from trajectory noise --
+      "hip2": a second HIP trainer (same seed; differs from the first only through the order of float atomics),
+      "emu":  the oracle with bf16 operand / dZ rounding emulated (same rounding points as the kernels, torch fp32 ops),
+      "hip32": a HIP trainer in the fp32 reference-precision mode (nerf_set_option("mlp_precision", 32) per step)."""
     torch.set_num_threads(threads)
     if oracle_device != "cpu":
         torch.backends.cuda.matmul.allow_tf32 = False                  # plain fp32 GEMMs for the checker
@@ -67,6 +71,16 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
                  seed=seed, device=dev, lrate_decay=lrate_decay, ref_quirks=quirks)
     ot = O.OracleTrainer(arch, 64, n_importance, seed=seed, lrate_decay=lrate_decay, ref_quirks=quirks, device=oracle_device)
     assert torch.equal(tr.coarse.params.cpu(), ot.pc.detach().cpu())
+    mk_hip = lambda: Trainer(imgs[:-test_views], poses[:-test_views], K, N_rand=n_rand, n_depth_samples=64,
+                             N_importance=n_importance, seed=seed, device=dev, lrate_decay=lrate_decay, ref_quirks=quirks)
+    tr2 = mk_hip() if "hip2" in extra else None
+    tr32 = mk_hip() if "hip32" in extra else None
+    oe = O.OracleTrainer(arch, 64, n_importance, seed=seed, lrate_decay=lrate_decay, ref_quirks=quirks, device=oracle_device,
+                         emulate_bf16=True) if "emu" in extra else None
+    from nerf_meets_mlx_amd import _native
+
+    def precision(bits):
+        _native.check(_native.lib().nerf_set_option(b"mlp_precision", bits))
     g = torch.Generator().manual_seed(123)
     od = torch.device(oracle_device)
     NI = max(n_importance, 1)
@@ -78,7 +92,7 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
     test_rays = [eval_rays(p) for p in test_poses]
     u_eval = torch.rand(H * W, NI, generator=torch.Generator().manual_seed(7))
 
-    def oracle_psnr():
+    def oracle_psnr(ot=ot):
         with torch.no_grad():
             pc = O.unflatten_params(arch, ot.pc.detach())
             pf = O.unflatten_params(arch, ot.pf.detach()) if ot.pf is not None else None
@@ -97,7 +111,7 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
                 vals.append(float(O.psnr(rgb, img.reshape(-1, 3).to(od))))
         return float(np.mean(vals))
 
-    def hip_psnr():
+    def hip_psnr(tr=tr):
         vals = []
         for img, rays in zip(test_imgs, test_rays):
             rgb = tr.render_rays(rays, u=u_eval.to(dev) if n_importance > 0 else None)
@@ -111,10 +125,26 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
         u = torch.rand(n_rand, NI, generator=g)
         lh = tr.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
         lo = ot.step(rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od), u.to(od))
+        if tr2 is not None:
+            tr2.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
+        if tr32 is not None:
+            precision(32)
+            tr32.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
+            precision(16)
+        if oe is not None:
+            oe.step(rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od), u.to(od))
         if it % every == 0 or it == iters:
             rec = {"iter": it, "psnr_hip": hip_psnr(), "psnr_oracle": oracle_psnr(),
                    "loss_coarse_hip": float(lh["loss_coarse"]), "loss_coarse_oracle": lo["loss_coarse"],
                    "elapsed_s": time.time() - t0}
+            if tr2 is not None:
+                rec["psnr_hip2"] = hip_psnr(tr2)
+            if tr32 is not None:
+                precision(32)
+                rec["psnr_hip32"] = hip_psnr(tr32)
+                precision(16)
+            if oe is not None:
+                rec["psnr_oracle_emu_bf16"] = oracle_psnr(oe)
             if n_importance > 0:
                 rec["loss_fine_hip"], rec["loss_fine_oracle"] = float(lh["loss_fine"]), lo["loss_fine"]
             rec["delta_db"] = rec["psnr_hip"] - rec["psnr_oracle"]
@@ -138,10 +168,12 @@ def main():
     ap.add_argument("--oracle-device", default="cpu", help="cpu | cuda: where the fp32 oracle trainer runs")
     ap.add_argument("--seed", type=int, default=-1, help="-1: first seed whose coarse AND fine nets start with sigma > 0")
     ap.add_argument("--no-quirks", action="store_true")
+    ap.add_argument("--extra", default="", help="comma list of extra witnesses: hip2, emu, hip32 (see run())")
     a = ap.parse_args()
     run(hw=a.hw, n_rand=a.n_rand, iters=a.iters, every=a.every, views=a.views, test_views=a.test_views,
         n_importance=a.n_importance, seed=a.seed, quirks=not a.no_quirks, lrate_decay=a.lrate_decay,
         oracle_device=a.oracle_device, eval_chunk=a.eval_chunk, threads=a.threads,
+        extra=tuple(x for x in a.extra.split(",") if x),
         emit=lambda rec: print(json.dumps(rec), flush=True))
 
 
