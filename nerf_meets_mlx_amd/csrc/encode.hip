@@ -105,33 +105,45 @@ __global__ void __launch_bounds__(256) ngp_dir_rows_kernel(const float* __restri
   }
 }
 
+// Table-gradient scatter.  The scatter is bound by atomic REQUESTS at the memory side (one per cache line touched by a
+// wave instruction, ~20 G/s), not by bytes, so the lane mapping is chosen to make the lanes of one atomic instruction
+// fall into as few lines as possible: 2 F consecutive lanes serve one sample -- lane (f, dx) adds feature f into the
+// corner with x = floor (dx = 0) or x = ceil (dx = 1).  The hash is c_x ^ (c_y P1) ^ (c_z P2): for fixed (c_y, c_z) the
+// two x-neighbours differ only in the low bits of the index (same 128-byte line unless a carry crosses bit 3 for
+// F = 2: 15 of 16 cases), so one instruction touches ~16 lines for 64 lanes where the per-(sample, feature) mapping
+// touched 32 and the per-sample mapping 64.  Each lane issues the 4 (y, z) corner combinations of its x plane.
 template <int F, int LG>
 __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t M,
                                                            float* __restrict__ d_tables, const float* __restrict__ d_out,
                                                            int L, uint32_t T, ResTab rt) {
   const int l0 = blockIdx.y * LG;
   const uint32_t mask = T - 1;
-  const int64_t total = M * F;
+  const int64_t total = M * (2 * F);
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = t / F; const int f = (int)(t - m * F);
+    const int64_t m = t / (2 * F);
+    const int q = (int)(t - m * (2 * F)), f = q % F, dx = q / F;
     float px, py, pz;
     point_of(ps, m, px, py, pz);
 #pragma unroll
     for (int li = 0; li < LG; ++li) {
       const int l = l0 + li;
       if (l >= L) break;
-      const Corners c = corners_of(px, py, pz, rt.res[l], mask);
+      const float r = rt.res[l];
+      // same roundings as corners_of (hash_common.h): xs = p * r, floor / ceil, offset = xs - floor
+      const float xs = px * r, ys = py * r, zs = pz * r;
+      const float fx = floorf(xs), fy = floorf(ys), fz = floorf(zs);
+      const float ox = xs - fx, oy = ys - fy, oz = zs - fz;
+      const uint32_t cx = (uint32_t)(int32_t)(dx ? ceilf(xs) : fx);
+      const uint32_t yf = (uint32_t)(int32_t)fy * 2654435761u, yc = (uint32_t)(int32_t)ceilf(ys) * 2654435761u;
+      const uint32_t zf = (uint32_t)(int32_t)fz * 805459861u, zc = (uint32_t)(int32_t)ceilf(zs) * 805459861u;
       float* tb = d_tables + (size_t)l * T * F + f;
       const float g = d_out[(m * L + l) * F + f];
-      const float wx1 = c.ox, wx0 = 1 - c.ox, wy1 = c.oy, wy0 = 1 - c.oy, wz1 = c.oz, wz0 = 1 - c.oz;
-      atomicAdd(tb + (size_t)c.i[0] * F, g * wz1 * wy1 * wx1);
-      atomicAdd(tb + (size_t)c.i[3] * F, g * wz1 * wy1 * wx0);
-      atomicAdd(tb + (size_t)c.i[1] * F, g * wz1 * wy0 * wx1);
-      atomicAdd(tb + (size_t)c.i[2] * F, g * wz1 * wy0 * wx0);
-      atomicAdd(tb + (size_t)c.i[4] * F, g * wz0 * wy1 * wx1);
-      atomicAdd(tb + (size_t)c.i[7] * F, g * wz0 * wy1 * wx0);
-      atomicAdd(tb + (size_t)c.i[5] * F, g * wz0 * wy0 * wx1);
-      atomicAdd(tb + (size_t)c.i[6] * F, g * wz0 * wy0 * wx0);
+      // products in the order of the per-corner form (g * wz * wy * wx), so every addend is bit-identical to it
+      const float wx = dx ? ox : 1 - ox;
+      atomicAdd(tb + (size_t)((cx ^ yc ^ zc) & mask) * F, g * oz * oy * wx);
+      atomicAdd(tb + (size_t)((cx ^ yf ^ zc) & mask) * F, g * oz * (1 - oy) * wx);
+      atomicAdd(tb + (size_t)((cx ^ yc ^ zf) & mask) * F, g * (1 - oz) * oy * wx);
+      atomicAdd(tb + (size_t)((cx ^ yf ^ zf) & mask) * F, g * (1 - oz) * (1 - oy) * wx);
     }
   }
 }
@@ -149,7 +161,7 @@ static int launch_hashgrid(const float* x, int64_t M, const float* tables, float
   for (int l = 0; l < L; ++l) rt.res[l] = (float)res[l];
   const uint32_t T = 1u << log2_T;
   constexpr int LG = 4;                                   // levels per thread: LG x F contiguous floats per sample
-  const dim3 g(grid_for(BWD ? M * F : M, 256), (unsigned)((L + LG - 1) / LG)), b(256);
+  const dim3 g(grid_for(BWD ? M * F * 2 : M, 256, 256 * 32), (unsigned)((L + LG - 1) / LG)), b(256);
   auto st = as_stream(stream);
 #define HG(FF) do { if (BWD) hipLaunchKernelGGL((hashgrid_bwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, d_tables, d_out, L, T, rt); \
                     else hipLaunchKernelGGL((hashgrid_fwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, tables, L, T, rt, out, \

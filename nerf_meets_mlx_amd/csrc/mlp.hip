@@ -1244,7 +1244,16 @@ struct DwArgs {
   const void* acts;
   const void* dz;
   float* grads;
+  float* partial;         // [workgroup][DW_SLOT_FLOATS] split-K partial tiles (deterministic two-stage reduction)
 };
+// One slot per dW workgroup: up to 8 x 8 output tiles of 32 x 32 floats (tile (nt, kt) at (8 nt + kt) * 1024, row-major
+// inside the tile) + 8 x 32 bias partial sums.  The workgroups of a job write their partial dW here with plain
+// coalesced stores and mlp_dw_reduce_kernel adds the splits of every element in a FIXED order: no float atomics (they
+// cost 12.6 % of the dW kernel: 157 MB of read-modify-writes at the memory side per launch, whatever the batch size) and
+// the gradient is bit-reproducible from run to run -- with atomics the order of the adds, hence the rounding, was not.
+constexpr int DW_SLOT_FLOATS = 64 * 1024 + 256;
+constexpr int DW_MAX_WGS = 512;
+constexpr int64_t DW_PARTIAL_BYTES = (int64_t)DW_MAX_WGS * DW_SLOT_FLOATS * 4;
 
 constexpr int DW_FRAG_STRIDE = 1152;                 // 1 KiB + 128 B: neighbouring fragments hit disjoint banks
 constexpr int DW_STAGE_BYTES = 32 * DW_FRAG_STRIDE;  // 16 dZ + 16 act fragments per 32-sample tile
@@ -1378,10 +1387,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) mlp_dw_kernel(DwArgs a) {
     }
   }
   if (!active) return;
-#if NERF_ABLATE == 6          // timing-only build 6: no atomic epilogue
+#if NERF_ABLATE == 6          // timing-only build 6: no epilogue
   if (a.ntiles > 0) return;
 #endif
   const int rr = lane & 31, hh = lane >> 5;
+  float* slot = a.partial + (size_t)blockIdx.x * DW_SLOT_FLOATS;
 #pragma unroll
   for (int i = 0; i < DW_NPW; ++i) {
     const int nt = wr * DW_NPW + i;
@@ -1390,19 +1400,50 @@ __global__ void __launch_bounds__(64 * DW_WAVES) mlp_dw_kernel(DwArgs a) {
     for (int k = 0; k < 2; ++k) {
       const int kt = wc * 2 + k;
       if (kt >= k_tiles) continue;
-      const int col = 32 * kt + rr;
-      if (col >= jb.k_valid) continue;
+      float* tile = slot + (8 * nt + kt) * 1024;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = 32 * nt + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (n < jb.n_valid) atomicAdd(a.grads + jb.w_off + (int64_t)n * jb.ldw + jb.col0 + col, acc[i][k][e]);
-      }
+      for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32 + rr] = acc[i][k][e];      // 128 B per half wave
     }
     if (wc == 0 && jb.b_off >= 0) {
       const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // the two sample halves of the k-step
-      const int n = 32 * nt + rr;
-      if (hh == 0 && n < jb.n_valid) atomicAdd(a.grads + jb.b_off + n, tot);
+      if (hh == 0) slot[64 * 1024 + 32 * nt + rr] = tot;
     }
+  }
+}
+
+// grads[w_off + n ldw + col0 + k] = sum over the job's splits of its partial tiles, in split order (deterministic);
+// blockIdx.y = job, one thread per output element (weights first, then the bias row of jobs that own one).  The S loads
+// of an element are independent (issued eight at a time), only the adds are a chain.
+__global__ void __launch_bounds__(256) mlp_dw_reduce_kernel(DwArgs a) {
+  const int j = blockIdx.y;
+  const DwJob jb = a.jobs[j];
+  int first = 0;
+  for (int q = 0; q < j; ++q) first += a.splits[q];
+  const int S = a.splits[j];
+  const int nw = jb.n_valid * jb.k_valid, nb = jb.b_off >= 0 ? jb.n_valid : 0;
+  const float* base = a.partial + (size_t)first * DW_SLOT_FLOATS;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < nw + nb; t += gridDim.x * 256) {
+    const float* src;
+    float* dst;
+    if (t < nw) {
+      const int n = t / jb.k_valid, k = t - n * jb.k_valid;
+      src = base + (8 * (n >> 5) + (k >> 5)) * 1024 + (n & 31) * 32 + (k & 31);
+      dst = a.grads + jb.w_off + (int64_t)n * jb.ldw + jb.col0 + k;
+    } else {
+      src = base + 64 * 1024 + (t - nw);
+      dst = a.grads + jb.b_off + (t - nw);
+    }
+    float sum = 0.0f;
+    int sidx = 0;
+    for (; sidx + 8 <= S; sidx += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(src + (size_t)(sidx + q) * DW_SLOT_FLOATS);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sum += v[q];
+    }
+    for (; sidx < S; ++sidx) sum += __builtin_nontemporal_load(src + (size_t)sidx * DW_SLOT_FLOATS);
+    *dst = sum;
   }
 }
 
@@ -1983,7 +2024,8 @@ extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
-  const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16;
+  const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16
+                      + DW_PARTIAL_BYTES;                 // + the split-K partial tiles of the weight-gradient kernel
   return (k == 0 && g_mlp_precision == 32) ? f32::dz_bytes(M) : b16;
 }
 
@@ -2176,6 +2218,7 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   // for the 64-sample pass; with the old byte-only cost model 256 workgroups took 3.1 ms because the small jobs'
   // workgroups ran twice as long as the others.)  "dw_workgroups" overrides the total.
   int target_wgs = g_dw_wgs > 0 ? g_dw_wgs : cu_count();
+  if (target_wgs > DW_MAX_WGS) target_wgs = DW_MAX_WGS;          // one partial-tile slot per workgroup
   const int64_t max_splits = (ntiles + 3) / 4;                  // >= 4 sample tiles per workgroup
   int nw = 0;
   double frac[DW_MAX_JOBS];
@@ -2202,15 +2245,23 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
     if (d.splits[big] <= 1) break;
     d.splits[big] -= 1; nw -= 1;
   }
-  hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * nparams, s);
-  if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
+  if (g_dw_job_mask) {          // diagnostic subset of jobs: the parameters of the jobs left out read as zero
+    hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * nparams, s);
+    if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
+  }
+  NERF_REQUIRE(nw <= DW_MAX_WGS, NERF_E_SHAPE, "nerf_mlp_backward: dw_workgroups must be <= %d", DW_MAX_WGS);
   d.ntiles = (int)ntiles; d.astride = astride; d.zstride = zstride;
   d.acts = acts; d.dz = dz; d.grads = grads;
+  // the partial-tile slots live behind the dZ fragment blocks in the caller's dz workspace (nerf_mlp_dz_bytes counts them)
+  d.partial = reinterpret_cast<float*>(static_cast<char*>(dz) + padded_tiles(ntiles * 32) * zstride * 16);
   static DevOnce lds_attr_set;
   if (lds_attr_set.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
   hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
-  return check_launch("mlp dW");
+  int rc = check_launch("mlp dW");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(257, nj), dim3(256), 0, s, d);        // 256 x 256 weights + 256 biases: one element per thread
+  return check_launch("mlp dW reduce");
 }
 
 static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,

@@ -44,12 +44,18 @@ def alive_seed(arch, q, start=0):
 
 
 def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_importance=128, seed=-1, quirks=True,
-        lrate_decay=500, oracle_device="cpu", eval_chunk=8192, threads=16, emit=None, dev="cuda", extra=()):
+        lrate_decay=500, oracle_device="cpu", eval_chunk=8192, threads=16, emit=None, dev="cuda", extra=(), cross=False,
+        oracle_until=None):
     """Returns the list of checkpoint records; `emit(rec)` is called as they are produced.
     extra: witnesses trained on the same batches to separate precision from trajectory noise --
       "hip2": a second HIP trainer (same seed; differs from the first only through the order of float atomics),
       "emu":  the oracle with bf16 operand / dZ rounding emulated (same rounding points as the kernels, torch fp32 ops),
-      "hip32": a HIP trainer in the fp32 reference-precision mode (nerf_set_option("mlp_precision", 32) per step)."""
+      "hip32": a HIP trainer in the fp32 reference-precision mode (nerf_set_option("mlp_precision", 32) per step).
+    cross: at every checkpoint also compare the two implementations ON THE SAME PARAMETERS (no trajectory involved):
+      the oracle renders the HIP trainer's weights and the HIP renderer the oracle's (PSNR differences in dB), and both
+      compute the coarse / fine gradient of the current batch at the HIP trainer's weights (cosine, rel-L2).  Training is
+      chaotic -- two fp32 implementations drift +-1 dB apart after ~1500 iterations (profiles/r02_psnr_free_running_*) --
+      so this, not the free-running difference, is what isolates arithmetic from trajectory."""
     torch.set_num_threads(threads)
     if oracle_device != "cpu":
         torch.backends.cuda.matmul.allow_tf32 = False                  # plain fp32 GEMMs for the checker
@@ -92,10 +98,11 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
     test_rays = [eval_rays(p) for p in test_poses]
     u_eval = torch.rand(H * W, NI, generator=torch.Generator().manual_seed(7))
 
-    def oracle_psnr(ot=ot):
+    def oracle_psnr(ot=ot, flat=None):
         with torch.no_grad():
-            pc = O.unflatten_params(arch, ot.pc.detach())
-            pf = O.unflatten_params(arch, ot.pf.detach()) if ot.pf is not None else None
+            fc, ff = (ot.pc.detach(), ot.pf.detach() if ot.pf is not None else None) if flat is None else flat
+            pc = O.unflatten_params(arch, fc)
+            pf = O.unflatten_params(arch, ff) if ff is not None else None
             vals = []
             for img, rays in zip(test_imgs, test_rays):
                 rays_o = rays.to(od)
@@ -118,13 +125,74 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
             vals.append(float(10.0 * torch.log10(1.0 / torch.mean((rgb - img.reshape(-1, 3)) ** 2))))
         return float(np.mean(vals))
 
+    probe = mk_hip() if cross else None
+    from nerf_meets_mlx_amd import sampling
+    from nerf_meets_mlx_amd.ops.metric import mse_loss_grad
+    from nerf_meets_mlx_amd.rendering import render as R
+
+    def hip_net_grad(model, rays, z, target, white):
+        raw = model.query(rays, z, ref_quirks=quirks, train=True)
+        rgb, _, _, weights, _ = R.composite(raw, z, rays, 0.0, white)
+        loss, d_rgb = mse_loss_grad(rgb, target)
+        return model.backward(R.composite_backward(raw, z, rays, d_rgb, white)).clone(), float(loss), weights
+
+    def cross_check(rays, target, u):
+        """Both implementations at the HIP trainer's CURRENT weights, on the batch it just trained on."""
+        out = {}
+        hc = tr.coarse.params.detach().clone()
+        hf = tr.fine.params.detach().clone() if tr.fine is not None else None
+        out["psnr_oracle_renders_hip_weights"] = oracle_psnr(flat=(hc.to(od), hf.to(od) if hf is not None else None))
+        probe.coarse.load_flat(ot.pc.detach())
+        if probe.fine is not None:
+            probe.fine.load_flat(ot.pf.detach())
+        out["psnr_hip_renders_oracle_weights"] = hip_psnr(probe)
+        # gradients at the HIP weights
+        probe.coarse.load_flat(hc)
+        if probe.fine is not None:
+            probe.fine.load_flat(hf)
+        z = sampling.sample_coarse(rays, 64)
+        gc, lc, wts = hip_net_grad(probe.coarse, rays, z, target, True)
+        fl = hc.to(od).clone().requires_grad_(True)
+        ro, rd, tg = rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od)
+        prays = O.pack_rays(ro, rd, 2.0, 6.0)
+        lco, rco = O.coarse_loss(arch, O.unflatten_params(arch, fl), prays, tg, 64, True, quirks)
+        gco, = torch.autograd.grad(lco, fl)
+        def cosv(a, b):
+            """cosine; a network that is dead under the reference's formulas (sigma < 0 everywhere: alpha == 0, DESIGN.md
+            section 7) has an EXACTLY zero gradient in both implementations: that agreement counts as 1, a one-sided zero as 0"""
+            na, nb = float(a.double().norm()), float(b.double().norm())
+            if na == 0.0 or nb == 0.0:
+                return 1.0 if na == nb else 0.0
+            return float(torch.nn.functional.cosine_similarity(a.double().reshape(1, -1), b.double().reshape(1, -1)))
+
+        def rl2(a, b):
+            nb = float(b.double().norm())
+            return float((a.double() - b.double()).norm()) / nb if nb > 0 else float(a.double().norm())
+        out.update({"grad_coarse_cos": cosv(gc.to(od), gco), "grad_coarse_rel_l2": rl2(gc.to(od), gco),
+                    "loss_coarse_hip_at_w": lc, "loss_coarse_oracle_at_w": float(lco)})
+        if hf is not None:
+            _, zf = sampling.importance_sample(z, wts, n_importance, u=u.to(dev))
+            gf, lf, _ = hip_net_grad(probe.fine, rays, zf, target, not quirks)
+            with torch.no_grad():
+                z_imp = O.sample_from_inverse_cdf(rco["z_vals"], rco["weights"].detach(), u.to(od))
+                zfo = O.merge_sorted(rco["z_vals"], z_imp)
+            flf = hf.to(od).clone().requires_grad_(True)
+            lfo, _ = O.fine_loss(arch, O.unflatten_params(arch, flf), prays, zfo, tg, quirks)
+            gfo, = torch.autograd.grad(lfo, flf)
+            out.update({"grad_fine_cos": cosv(gf.to(od), gfo), "grad_fine_rel_l2": rl2(gf.to(od), gfo),
+                        "loss_fine_hip_at_w": lf, "loss_fine_oracle_at_w": float(lfo)})
+        return out
+
     recs = []
     t0 = time.time()
+    lo = {"loss_coarse": float("nan"), "loss_fine": float("nan")}
     for it in range(1, iters + 1):
         rays, target = tr.sample_batch()
         u = torch.rand(n_rand, NI, generator=g)
         lh = tr.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
-        lo = ot.step(rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od), u.to(od))
+        oracle_live = oracle_until is None or it <= oracle_until      # after that the oracle only cross-checks
+        if oracle_live:
+            lo = ot.step(rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od), u.to(od))
         if tr2 is not None:
             tr2.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
         if tr32 is not None:
@@ -134,9 +202,12 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
         if oe is not None:
             oe.step(rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od), u.to(od))
         if it % every == 0 or it == iters:
-            rec = {"iter": it, "psnr_hip": hip_psnr(), "psnr_oracle": oracle_psnr(),
-                   "loss_coarse_hip": float(lh["loss_coarse"]), "loss_coarse_oracle": lo["loss_coarse"],
+            rec = {"iter": it, "psnr_hip": hip_psnr(), "psnr_oracle": oracle_psnr() if oracle_live else None,
+                   "loss_coarse_hip": float(lh["loss_coarse"]), "loss_coarse_oracle": lo["loss_coarse"] if oracle_live else None,
                    "elapsed_s": time.time() - t0}
+            if cross:
+                rec.update(cross_check(rays, target, u))
+                rec["delta_db_same_weights"] = rec["psnr_hip"] - rec["psnr_oracle_renders_hip_weights"]
             if tr2 is not None:
                 rec["psnr_hip2"] = hip_psnr(tr2)
             if tr32 is not None:
@@ -146,8 +217,8 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
             if oe is not None:
                 rec["psnr_oracle_emu_bf16"] = oracle_psnr(oe)
             if n_importance > 0:
-                rec["loss_fine_hip"], rec["loss_fine_oracle"] = float(lh["loss_fine"]), lo["loss_fine"]
-            rec["delta_db"] = rec["psnr_hip"] - rec["psnr_oracle"]
+                rec["loss_fine_hip"], rec["loss_fine_oracle"] = float(lh["loss_fine"]), lo["loss_fine"] if oracle_live else None
+            rec["delta_db"] = rec["psnr_hip"] - rec["psnr_oracle"] if oracle_live else None
             recs.append(rec)
             emit(rec)
     return recs
@@ -169,11 +240,13 @@ def main():
     ap.add_argument("--seed", type=int, default=-1, help="-1: first seed whose coarse AND fine nets start with sigma > 0")
     ap.add_argument("--no-quirks", action="store_true")
     ap.add_argument("--extra", default="", help="comma list of extra witnesses: hip2, emu, hip32 (see run())")
+    ap.add_argument("--cross", action="store_true", help="same-weights cross checks at every checkpoint (see run())")
+    ap.add_argument("--oracle-until", type=int, default=None, help="stop stepping the oracle trainer after this iteration")
     a = ap.parse_args()
     run(hw=a.hw, n_rand=a.n_rand, iters=a.iters, every=a.every, views=a.views, test_views=a.test_views,
         n_importance=a.n_importance, seed=a.seed, quirks=not a.no_quirks, lrate_decay=a.lrate_decay,
         oracle_device=a.oracle_device, eval_chunk=a.eval_chunk, threads=a.threads,
-        extra=tuple(x for x in a.extra.split(",") if x),
+        extra=tuple(x for x in a.extra.split(",") if x), cross=a.cross, oracle_until=a.oracle_until,
         emit=lambda rec: print(json.dumps(rec), flush=True))
 
 
