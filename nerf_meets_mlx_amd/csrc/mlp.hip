@@ -892,10 +892,13 @@ __device__ __forceinline__ bf16x8 pe16_dir(const Pe16& q, const float (&x)[3]) {
   return k;
 }
 
-// out[s][nt>>1] (elements 4 (nt&1) + i) = act( W[16-row tile nt] . in[s] + bias ), s = 0..NS-1 sample tiles of 16
-template <int NS, int KS, int NT, bool RELU, class WS>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// out[s][nt>>1] (elements 4 (nt&1) + i) = act( W[16-row tile nt] . in[s] + bias ), s = 0..NS-1 sample tiles of 16.
+// hook(nt * KS + ks) runs behind the MFMAs of k-step (nt, ks): a place to put independent VALU work (the NEXT pass's
+// positional encoding) in the shadow of the matrix pipe; the slot index is a constant at every call site after unrolling.
+template <int NS, int KS, int NT, bool RELU, class WS, class HOOK = NoHook>
 __device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, const bf16x8 (&in)[NS][KS],
-                                            bf16x8 (&out)[NS][NT / 2], int lane) {
+                                            bf16x8 (&out)[NS][NT / 2], int lane, const HOOK& hook = HOOK()) {
   const int g = lane >> 4;
   f32x4 prev[NS];
   // epilogue of a finished tile, run under the next tile's MFMAs.  The empty asm pins it there: without it hipcc
@@ -926,6 +929,7 @@ __device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, co
       if (nt > 0 && ks == KS / 2) finish(nt - 1, prev);      // previous tile's epilogue, half a tile of MFMAs later
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, in[s][ks], acc[s], 0, 0, 0);
+      hook(nt * KS + ks);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) prev[s] = acc[s];
@@ -933,31 +937,112 @@ __device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, co
   finish(NT - 1, prev);
 }
 
-// one wave: NS x 16 samples starting at sample wtile * 16 NS
-template <int NS, class WS>
-__device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wtile0, int64_t nwtiles, int lane) {
-  const int c = lane & 15, g = lane >> 4;
-  const int64_t wtile = wtile0 < nwtiles ? wtile0 : nwtiles - 1;
-  bf16x8 pe[NS][2], dpe[NS][1];
-  const Pe16 pq = pe16_setup(a.fr, g);
+// 1 = compute the NEXT pass's encodings pair by pair behind the MFMAs of pos6 (ray loads) / pos7 (arithmetic) instead of
+// at the top of the pass, where the arithmetic of all 8 lock-stepped waves leaves the matrix pipe idle (4.3 % of the
+// pass's cycles by ablation).  Measured round 2 (profiles/r02_pe_hoist_ab.log, parity tests green with it): 8 waves x 32
+// samples 4.66 ms with and without, 4 waves x 64 samples 4.92 vs 4.82 ms (worse) -- the kernel is power-limited, the
+// cycles saved come back as a lower clock, and the hoist costs 28 VGPRs.  Kept as a negative result, off.
+#ifndef NERF_PE_HOIST
+#define NERF_PE_HOIST 0
+#endif
+#if NERF_ABLATE == 3          // the encoding-free timing build computes its placeholder at the top of the pass
+#undef NERF_PE_HOIST
+#define NERF_PE_HOIST 0
+#endif
+// The encodings of one wave's NS x 16 samples, and the raw ray data they are made from
+template <int NS> struct PeRegs { bf16x8 pe[NS][2], dpe[NS][1]; };
+template <int NS> struct PeRaw { float o[NS][3], d[NS][3], v[NS][3], z[NS]; };
+template <int NS>
+__device__ __forceinline__ void pe16_load(const FwdArgs& a, int64_t wtile, int c, PeRaw<NS>& r) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     int64_t m = wtile * (16 * NS) + 16 * s + c; if (m >= a.M) m = a.M - 1;
     const int64_t ray = (int64_t)((unsigned)m / (unsigned)a.n);
     const float* rr = a.rays + ray * NERF_RAY_STRIDE;
-    const float zv = a.z[m];
-    float p[3], d[3];
+    r.z[s] = a.z[m];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { p[k] = rr[k] + zv * rr[3 + k]; d[k] = rr[8 + k]; }
+    for (int k = 0; k < 3; ++k) { r.o[s][k] = rr[k]; r.d[s][k] = rr[3 + k]; r.v[s][k] = rr[8 + k]; }
+  }
+}
+// pair j of one sample: j 0..7 = position slots (2 j, 2 j + 1) -> pe[j >> 2] elements 2 (j & 3), +1; j 8..11 = direction
+template <int NS>
+__device__ __forceinline__ void pe16_pair(const Pe16& q, const float (&p)[3], const float (&d)[3], int j, PeRegs<NS>& out, int s) {
+  auto slot = [&](int sl) -> float {              // position slot sl of this lane group (see pos_chan16)
+    if (sl < 12) return sin_rev(p[sl % 3], sl < 6 ? q.fa : q.fb, (sl % 6) >= 3 ? 0.25f : 0.0f);
+    if (sl < 15) return sin_rev(p[sl - 12], q.fc, q.phc);
+    return q.g == 0 ? p[0] : q.g == 1 ? p[1] : q.g == 2 ? p[2] : 0.0f;
+  };
+  auto dslot = [&](int sl) -> float {             // direction slot (see dir_chan16)
+    if (sl < 6) return sin_rev(d[sl % 3], q.fd, sl >= 3 ? 0.25f : 0.0f);
+    if (sl == 6) return q.g == 0 ? d[0] : q.g == 1 ? d[1] : q.g == 2 ? d[2] : 0.0f;
+    return 0.0f;
+  };
+  if (j < 8) {
+    const bf16x2 pr = pack2(slot(2 * j), slot(2 * j + 1));
+    out.pe[s][j >> 2][2 * (j & 3)] = pr[0]; out.pe[s][j >> 2][2 * (j & 3) + 1] = pr[1];
+  } else {
+    const bf16x2 pr = pack2(dslot(2 * (j - 8)), dslot(2 * (j - 8) + 1));
+    out.dpe[s][0][2 * (j - 8)] = pr[0]; out.dpe[s][0][2 * (j - 8) + 1] = pr[1];
+  }
+}
+template <int NS>
+__device__ __forceinline__ void pe16_all(const FwdArgs& a, const Pe16& pq, int64_t wtile, int c, PeRegs<NS>& out) {
+  PeRaw<NS> r;
+  pe16_load<NS>(a, wtile, c, r);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = r.o[s][k] + r.z[s] * r.d[s][k];          // render.py:142
 #if NERF_ABLATE == 3          // timing-only build 3: no positional-encoding arithmetic
     bf16x8 cst;
-    for (int j = 0; j < 8; ++j) cst[j] = (__bf16)(p[0] + d[0]);
-    pe[s][0] = cst; pe[s][1] = cst; dpe[s][0] = cst;
+    for (int j = 0; j < 8; ++j) cst[j] = (__bf16)(p[0] + r.v[s][0]);
+    out.pe[s][0] = cst; out.pe[s][1] = cst; out.dpe[s][0] = cst;
 #else
-    pe16_pos(pq, p, pe[s][0], pe[s][1]);
-    dpe[s][0] = pe16_dir(pq, d);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) pe16_pair<NS>(pq, p, r.v[s], j, out, s);
 #endif
   }
+}
+
+// one wave: NS x 16 samples starting at sample wtile * 16 NS.  `cur` holds this tile's encodings on entry and the NEXT
+// tile's (wtile_next) on return: they are produced pair by pair behind the MFMAs of pos6 (ray loads) and pos7
+// (arithmetic) -- the position fragments are dead after pos5, so they are overwritten in place; only the direction
+// fragment needs a second copy until the view layer has read it.  Done at the top of a pass, the encoding arithmetic of
+// all 8 waves (in lockstep behind the ring barrier) left the matrix pipe idle for 4.3 % of the pass.
+template <int NS, class WS>
+__device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wtile0, int64_t wtile_next, int64_t nwtiles,
+                                            int lane, PeRegs<NS>& cur) {
+  const int c = lane & 15, g = lane >> 4;
+  const Pe16 pq = pe16_setup(a.fr, g);
+  bf16x8 (&pe)[NS][2] = cur.pe;
+  bf16x8 (&dpe)[NS][1] = cur.dpe;
+  PeRaw<NS> raw;
+  PeRegs<NS> nxt;                 // only nxt.dpe is used (position fragments are written into cur.pe in place)
+  float pn[NS][3];
+  const int64_t wt_n = wtile_next < nwtiles ? wtile_next : nwtiles - 1;
+  auto hook_load = [&](int slot) {
+    if (NERF_PE_HOIST && slot == 0) pe16_load<NS>(a, wt_n, c, raw);
+  };
+  auto hook_math = [&](int slot) {
+    if (!NERF_PE_HOIST) return;
+    if (slot == 0) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pn[s][k] = raw.o[s][k] + raw.z[s] * raw.d[s][k];
+    }
+    // 12 NS pairs over the remaining slots of the layer (128 k-steps): one pair every 4th slot (NS <= 2) / 2nd slot
+    constexpr int EVERY = NS <= 2 ? 4 : 2;
+    if (slot >= 4 && (slot % EVERY) == 0) {
+      const int idx = (slot - 4) / EVERY;
+      if (idx < 12 * NS) {
+        const int s = idx / 12, j = idx % 12;
+        if (j < 8) pe16_pair<NS>(pq, pn[s], raw.v[s], j, cur, s);      // in place: pos5 was the last reader
+        else pe16_pair<NS>(pq, pn[s], raw.v[s], j, nxt, s);
+      }
+    }
+  };
   bf16x8 ha[NS][8], hb[NS][8];
   layer_fwd16<NS, 2, 16, true>(ws, L16::F_L0, 0, pe, ha, lane);
   layer_fwd16<NS, 8, 16, true>(ws, L16::F_L1 + 0 * 128, 256, ha, hb, lane);
@@ -974,8 +1059,8 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wt
     }
     layer_fwd16<NS, 10, 16, true>(ws, L16::F_L5, 1280, cat, hb, lane);
   }
-  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L6, 1536, hb, ha, lane);
-  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L7, 1792, ha, hb, lane);
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L6, 1536, hb, ha, lane, hook_load);
+  layer_fwd16<NS, 8, 16, true>(ws, L16::F_L7, 1792, ha, hb, lane, hook_math);
   layer_fwd16<NS, 8, 16, false>(ws, L16::F_FA, L::BI_FEAT, hb, ha, lane);
   float alpha[NS];
   {
@@ -1025,6 +1110,10 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wt
       }
     }
   }
+  if (NERF_PE_HOIST) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) cur.dpe[s][0] = nxt.dpe[s][0];
+  }
 }
 
 // NW waves x NS sample tiles of 16 = 256 samples per workgroup pass either way: <8, 2> two waves per SIMD at 256
@@ -1043,11 +1132,20 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
   ring_load_bias(a.bias, L::BI_TOTAL);
   __syncthreads();
   NERF_STAMP_BEGIN();
+  PeRegs<NS> cur;
+  if (NERF_PE_HOIST) {
+    const int64_t first = (int64_t)blockIdx.x * NW + wv;
+    pe16_all<NS>(a, pe16_setup(a.fr, lane >> 4), first < nwtiles ? first : nwtiles - 1, lane & 15, cur);
+  }
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     ws.new_pass();
-    fwd_tiles16<NS>(a, ws, sp * NW + wv, nwtiles, ln);
+    if (!NERF_PE_HOIST) {
+      const int64_t wt = sp * NW + wv;
+      pe16_all<NS>(a, pe16_setup(a.fr, ln >> 4), wt < nwtiles ? wt : nwtiles - 1, ln & 15, cur);
+    }
+    fwd_tiles16<NS>(a, ws, sp * NW + wv, (sp + gridDim.x) * NW + wv, nwtiles, ln, cur);
     NERF_STAMP_PASS();
   }
   NERF_STAMP_END();

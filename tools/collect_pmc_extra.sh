@@ -33,7 +33,7 @@ with open("$O/pmc_mfma_lds.csv", "w") as fp:
         usb = b[k]["us:SQ_LDS_IDX_ACTIVE"]; selb = [i for i, u in enumerate(usb) if u > 0.6 * max(usb)]
         c = statistics.mean([b[k]["SQ_LDS_BANK_CONFLICT"][i] for i in selb]); ia = statistics.mean([b[k]["SQ_LDS_IDX_ACTIVE"][i] for i in selb])
         cyc = g / 8                      # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-        fp.write(f"{k[0]},{k[1]},{len(sel)},{t:.1f},{m:.0f},{g:.0f},{cyc / t / 1e3:.3f},{m / (cyc * 1024):.3f},{c:.0f},{ia:.0f},{c / max(ia, 1):.4f}\n")
+        fp.write(f"\"{k[0]}\",{k[1]},{len(sel)},{t:.1f},{m:.0f},{g:.0f},{cyc / t / 1e3:.3f},{m / (cyc * 1024):.3f},{c:.0f},{ia:.0f},{c / max(ia, 1):.4f}\n")
 print(open("$O/pmc_mfma_lds.csv").read())
 PY
 find $O/pmc_mfma $O/pmc_lds -type f -size +4M -delete

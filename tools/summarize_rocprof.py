@@ -21,6 +21,28 @@ def find(d, suffix):
     return hits[-1]
 
 
+# Dynamic LDS per workgroup of the kernels that ask for it at launch (rocprofv3's LDS_Block_Size column only shows the
+# STATIC size, 0 for these): the constants of csrc/mlp.hip / mlp32.hip / metric.hip.
+DYNAMIC_LDS = {
+    "mlp_fwd_ring16_kernel": 4 * 32 * 1024 + 2560 * 4,        # RING_LDS_BYTES: 4-stage x 32 KiB weight ring + bias slots
+    "mlp_fwd_ring_kernel": 4 * 32 * 1024 + 2560 * 4,
+    "mlp_bwd_ring_kernel": 4 * 32 * 1024 + 2560 * 4,
+    "mlp_img_fwd_ring_kernel": 4 * 32 * 1024 + 2560 * 4,
+    "mlp_img_bwd_ring_kernel": 4 * 32 * 1024 + 2560 * 4,
+    "mlp_dw_kernel": 4 * 32 * 1152 + 1024,                    # DW_LDS_BYTES: 4 stages x 32 fragments x 1152 B + sink
+    "mlp_small_fwd_kernel": 32 * 1024 + 288 * 4,              # LN::LDS_BYTES: resident fragment stream + biases
+    "mlp_small_bwd_kernel": 32 * 1024 + 288 * 4,
+    "mlp32_fwd_kernel": 4 * 256 * 32 * 4, "mlp32_bwd_kernel": 4 * 256 * 32 * 4,     # one 32 KiB slab per wave
+}
+
+
+def dynamic_lds(name):
+    for k, v in DYNAMIC_LDS.items():
+        if k in name:
+            return v
+    return 0
+
+
 def short(name):
     name = re.sub(r"^void ", "", name)
     return re.sub(r"\(nerf::\w+\)$|\(.*\)$", "", name)
@@ -52,9 +74,9 @@ def main():
             groups[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         with open(os.path.join(a.out, f"{R}_bench_kernel_trace_summary.csv"), "w", newline="") as fp:
             w = csv.writer(fp)
-            w.writerow(["kernel", "grid_x", "wg_x", "vgpr", "agpr", "lds", "scratch", "launches", "avg_us", "min_us", "max_us"])
+            w.writerow(["kernel", "grid_x", "wg_x", "vgpr", "agpr", "lds_static", "scratch", "lds_dynamic", "launches", "avg_us", "min_us", "max_us"])
             for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
-                w.writerow(list(k) + [len(v), f"{statistics.mean(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}"])
+                w.writerow(list(k) + [dynamic_lds(k[0]), len(v), f"{statistics.mean(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}"])
         # the render-path forward kernel, split by launch duration class (coarse 64 / fine 192 samples per ray)
         fwd = [(k, v) for k, v in groups.items() if "mlp_fwd_ring16_kernel" in k[0] or k[0].startswith("nerf::mlp_fwd_ring_kernel<1, false>")]
         with open(os.path.join(a.out, f"{R}_dominant_kernel_launches.csv"), "w", newline="") as fp:
