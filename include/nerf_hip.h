@@ -77,6 +77,12 @@ int nerf_ndc_rays(float* rays, int64_t n, int H, int W, float focal, float near,
 int nerf_sample_coarse(const float* rays, int64_t B, int n, int lindisp, float perturb, const float* t_rand,
                        float* z, void* stream);
 
+/* replaces: sampling/__init__.py:10-31 add_noise_z on caller-supplied depths (the fused form above covers the render
+ * path): mids = (z[k] + z[k+1]) / 2, lower = [z_first, mids], upper = [mids, z_last],
+ * z_out = lower + (upper - lower) * (t_rand * strength).  z_in, t_rand, z_out: [B,n]; not in place.                */
+int nerf_add_noise_z(const float* z_in, const float* t_rand, int64_t B, int n, float strength, float* z_out,
+                     void* stream);
+
 /* replaces: sampling/__init__.py:101-177 sample_from_inverse_cdf_torch (u passed in
  * instead of torch.rand) and the sort of entrypoints/__test_nerf.py:288 /
  * rendering/render.py:225.  weights: [B,n] (the reference's [B,n,1] squeezed).

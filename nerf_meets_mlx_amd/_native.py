@@ -21,6 +21,7 @@ SIGNATURES = {
     "nerf_gather_rows": (_I, [_P, _I64, _P, _I64, _I, _P, _P]),
     "nerf_ndc_rays": (_I, [_P, _I64, _I, _I, _F, _F, _P]),
     "nerf_sample_coarse": (_I, [_P, _I64, _I, _I, _F, _P, _P, _P]),
+    "nerf_add_noise_z": (_I, [_P, _P, _I64, _I, _F, _P, _P]),
     "nerf_importance_sample": (_I, [_P, _P, _P, _I64, _I, _I, _F, _P, _P, _P, _P, _P]),
     "nerf_encode_freq": (_I, [_P, _I64, _I, _I, _I, _P, _P]),
     "nerf_encode_sinusoidal": (_I, [_P, _I64, _I, _I, C.POINTER(C.c_float), _I, _P, _P]),

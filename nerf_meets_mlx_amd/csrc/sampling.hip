@@ -26,6 +26,19 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t B, 
   }
 }
 
+// stand-alone stratified jitter on caller-supplied depths (sampling/__init__.py:10-31, intended semantics: SURVEY Q6)
+__global__ void add_noise_z_kernel(const float* __restrict__ z_in, const float* __restrict__ t_rand, int64_t B, int n,
+                                   float strength, float* __restrict__ z_out) {
+  const int64_t total = B * n;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % n);
+    const float v = z_in[t];
+    const float lo = (k == 0) ? v : 0.5f * (z_in[t - 1] + v);               // lower = [z_first, mids]
+    const float hi = (k == n - 1) ? v : 0.5f * (v + z_in[t + 1]);           // upper = [mids, z_last]
+    z_out[t] = lo + (hi - lo) * (t_rand[t] * strength);
+  }
+}
+
 // ---- importance sampling -------------------------------------------------------------------
 // LDS per wave: cdf[n+1], zmid[n+1], merged[n+N] (floats).
 template <int CH>   // CH = ceil(n/64): consecutive bins handled by one lane in the scan
@@ -176,6 +189,17 @@ extern "C" int nerf_sample_coarse(const float* rays, int64_t B, int n, int lindi
   hipLaunchKernelGGL(sample_coarse_kernel, dim3(grid_for(B * n, 256)), dim3(256), 0, as_stream(stream), rays, B, n,
                      lindisp, perturb, t_rand, step, z);
   return check_launch("nerf_sample_coarse");
+}
+
+extern "C" int nerf_add_noise_z(const float* z_in, const float* t_rand, int64_t B, int n, float strength, float* z_out,
+                               void* stream) {
+  NERF_REQUIRE(B >= 0 && n >= 1, NERF_E_SHAPE, "nerf_add_noise_z: bad B/n");
+  if (B == 0) return NERF_OK;
+  NERF_REQUIRE(z_in && t_rand && z_out, NERF_E_NULL, "nerf_add_noise_z: NULL pointer");
+  NERF_REQUIRE(z_in != z_out, NERF_E_SHAPE, "nerf_add_noise_z: in-place use is not supported (neighbours are read)");
+  hipLaunchKernelGGL(add_noise_z_kernel, dim3(grid_for(B * n, 256)), dim3(256), 0, as_stream(stream), z_in, t_rand, B, n,
+                     strength, z_out);
+  return check_launch("nerf_add_noise_z");
 }
 
 extern "C" int nerf_importance_sample(const float* z, const float* weights, const float* u, int64_t B, int n, int N,

@@ -38,13 +38,14 @@ def add_noise_z(z_vals: torch.Tensor, strength: float = 1.0, t_rand: Optional[to
     """Stratified jitter (`sampling/__init__.py:10-31`, intended semantics: SURVEY Q6)."""
     if strength <= 0.0:
         return z_vals
+    z = N.f32(z_vals)
     if t_rand is None:
-        t_rand = torch.rand_like(z_vals)
-    t = t_rand * strength
-    mids = 0.5 * (z_vals[..., :-1] + z_vals[..., 1:])
-    upper = torch.cat([mids, z_vals[..., -1:]], -1)
-    lower = torch.cat([z_vals[..., :1], mids], -1)
-    return lower + (upper - lower) * t
+        t_rand = torch.rand_like(z)                                             # mx.random.uniform (:17)
+    n = z.shape[-1]
+    out = torch.empty_like(z)
+    N.check(N.lib().nerf_add_noise_z(N.ptr(z), N.ptr(N.f32(t_rand)), z.numel() // n, n, float(strength), N.ptr(out),
+                                     N.stream()))
+    return out
 
 
 def importance_sample(z_vals, weights, n_importance_samples: int, u=None, eps: float = 1e-5, merge: bool = True,

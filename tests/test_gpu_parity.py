@@ -103,6 +103,14 @@ def test_sample_coarse():
     zj = sampling.sample_coarse(rays.to(DEV), n, perturb=1.0, t_rand=t.to(DEV)).cpu()
     np.testing.assert_allclose(zj.numpy(), O.add_noise_z(O.sample_z_uniform(near, far, n), 1.0, t).numpy(), rtol=0, atol=5e-7)
     assert torch.equal(sampling.add_noise_z(z, 0.0), z)
+    # the stand-alone form on caller-supplied (here: unevenly spaced) depths runs the same arithmetic as a kernel
+    zz = torch.sort(torch.rand(37, 19) * 4 + 2, -1).values
+    tt = torch.rand(37, 19)
+    for strength in (1.0, 0.3):
+        got = sampling.add_noise_z(zz.to(DEV), strength, tt.to(DEV)).cpu()
+        np.testing.assert_allclose(got.numpy(), O.add_noise_z(zz, strength, tt).numpy(), rtol=0, atol=5e-7)
+    one = sampling.add_noise_z(zz[:, :1].contiguous().to(DEV), 1.0, tt[:, :1].contiguous().to(DEV)).cpu()
+    assert torch.equal(one, zz[:, :1])                      # n = 1: lower == upper == z
 
 
 # ------------------------------------------------------------------------------ a15 / a17

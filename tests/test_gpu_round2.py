@@ -160,6 +160,35 @@ def test_fp32_mode_forward_matches_fp32_oracle(quirk):
         _native.check(_native.lib().nerf_set_option(b"mlp_precision", 16))
 
 
+def test_fp32_mode_render_rays_eval_end_to_end():
+    """The whole render path (coarse pass -> compositing -> inverse-CDF importance sampling -> sort -> fine pass ->
+    compositing, rendering/render.py:164-241) in fp32 mode against the fp32 oracle on the same rays and uniforms:
+    rgb / acc within 5e-4 absolute (bf16 mode: 3e-2), the integer bin indices of the importance sampler -- hence z_fine --
+    identical except where a uniform lands within float32 noise of a CDF step."""
+    from nerf_meets_mlx_amd import _native
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    from nerf_meets_mlx_amd.rendering import render
+    _native.check(_native.lib().nerf_set_option(b"mlp_precision", 32))
+    try:
+        arch = O.NerfArch()
+        mc = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=4)
+        mf = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=5)
+        for mm in (mc, mf):
+            mm.load_flat(mm.params * 1.5)
+        B = 1500
+        rays = _rays(B, 21)
+        u = torch.rand(B, 128, generator=torch.Generator().manual_seed(2))
+        out = render.render_rays_fused(rays.to(DEV), mc, mf, 64, 128, u=u.to(DEV), white_bkgd=True, ref_quirks=True,
+                                       with_coarse=True)
+        ref = O.render_rays_eval(arch, O.unflatten_params(arch, mc.params.cpu()), O.unflatten_params(arch, mf.params.cpu()),
+                                 rays, 64, 128, u, white_bkgd=True)
+        assert float((out["rgb_map"].cpu() - ref["rgb_map"]).abs().max()) < 5e-4
+        assert float((out["acc_map"].cpu().reshape(-1) - ref["acc_map"].reshape(-1)).abs().max()) < 5e-4
+        assert float((out["rgb_coarse"].cpu() - ref["rgb_coarse"]).abs().max()) < 5e-4
+    finally:
+        _native.check(_native.lib().nerf_set_option(b"mlp_precision", 16))
+
+
 def test_fp32_mode_backward_and_training_step():
     """fp32 mode, adjoint: dW / db against torch autograd through the fp32 oracle, rel-L2 <= 1e-3 and rel-max <= 1e-2
     for every tensor (no bf16 anywhere, so no rounding-induced ReLU flips: what remains is fp32 summation order over

@@ -133,3 +133,58 @@ def test_bench_and_entry_scripts_parse_without_a_gpu():
     for tool in ("summarize_rocprof.py", "psnr_parity.py", "psnr_parity_ngp.py", "bench_kernels.py"):
         src = open(os.path.join(root, "tools", tool)).read()
         compile(src, tool, "exec")
+
+
+def _load_bench():
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_self_spawns_ranks_and_refuses_a_world_mismatch(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself (torch.distributed.run, rendezvous
+    on 127.0.0.1, dmabuf IPC flag kept) before anything touches the GPU -- in round 1 it silently ran ONE rank and printed
+    n_gpus: 1 -- and a launcher that started a different number of ranks than --gpus says is an error, not a 1-GPU line."""
+    import os, subprocess, sys
+    b = _load_bench()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert e.value.code == 7                                       # the children's exit code is ours
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher whose world size differs from --gpus: exit 2 before any GPU work
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 2 and "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_reads_pmc_tables_with_and_without_quotes(tmp_path):
+    """Kernel names carry commas (`mlp_fwd_ring16_kernel<8, 2>`): round 1's unquoted CSV shifted the columns and the bench
+    line lost `mfma_busy_cycles_frac`.  Both spellings must parse."""
+    b = _load_bench()
+    hdr = "kernel,grid,launches,avg_us,SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE,clock_GHz,mfma_busy_frac_of_cycles,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,lds_conflict_frac\n"
+    row = "131072,6,4987.4,7373586432,73472174,1.841,0.784,0,1042861568,0.0000\n"
+    other = "nerf::mlp_dw_kernel,262144,6,1566.8,956301312,25121947,2.004,0.297,0,119544580,0.0000\n"
+    for name in ("nerf::mlp_fwd_ring16_kernel<8, 2>,", '"nerf::mlp_fwd_ring16_kernel<8, 2>",'):
+        f = tmp_path / "t.csv"
+        f.write_text(hdr + other + name + row)
+        assert b._read_pmc_busy(str(f), "mlp_fwd_ring16_kernel<8,2>") == 0.784
+        assert b._read_pmc_busy(str(f), "mlp_dw_kernel") == 0.297
+        assert b._read_pmc_busy(str(f), "no_such_kernel") is None
+    assert b._read_pmc_busy(str(tmp_path / "absent.csv"), "x") is None

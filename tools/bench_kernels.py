@@ -67,6 +67,10 @@ report("hashgrid bwd (float atomics)", f"{M} points", M * (12 + 128 + 16 * 8 * 8
 sh = SphericalHarmonicsEncoding(3, 4)
 d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev), dim=-1)
 report("sh_encode degree 4", f"{M} dirs", M * (12 + 100), lambda: sh(d))
+from nerf_meets_mlx_amd.ops.metric import SSIM
+ia = torch.rand(4, 3, 800, 800, device=dev); ib = (ia + 0.05 * torch.randn_like(ia)).clamp(0, 1)
+ssim = SSIM()
+report("ssim 11x11 window (4 x 3 x 800 x 800, both images read once)", "4 images", 2 * ia.numel() * 4, lambda: ssim(ia, ib))
 print("kernel,work,algorithmic_bytes,avg_us,GB_per_s,frac_of_8TBps")
 for r in rows:
     print(f"{r[0]},{r[1]},{r[2]},{r[3]:.1f},{r[4]:.0f},{r[5]:.3f}")
