@@ -36,8 +36,8 @@ TRAIN_BYTES_PER_SAMPLE = (321 + 356 + 9) * 1024 / 32      # HBM bytes per sample
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (50 x ~12 ms: long enough for an SMI sampler to see the GPU busy)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n-rand", type=int, default=4096, help="training rays per GPU per step (argparse default of the reference)")
     ap.add_argument("--render-rays", type=int, default=32768, help="rays per render chunk per GPU per step")
     ap.add_argument("--hw", type=int, default=800)
