@@ -274,6 +274,8 @@ int nerf_comm_destroy(void* comm);
  *   "ring_workgroups" persistent workgroups of the ring kernels (0 = default: one per CU of the current device)
  *   "dw_workgroups"   0 auto (one per CU) | workgroups of the weight-gradient kernel
  *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)
+ *   "ring_split"      1 (default): one 8-wave workgroup per CU behind a 128 KiB weight ring; 2: two independent 4-wave
+ *                     workgroups behind 64 KiB rings (training forward / chain only; measured slower)
  *   "mlp_precision"   16 (default): bf16 MFMA operands, fp32 accumulate -- the benchmarked mode (BASELINE configs[1-3]);
  *                     32: the reference's own arithmetic -- float32 operands on v_mfma_f32_32x32x2_f32, sinf / cosf
  *                     encodings (models/NeRF.py:201-243 runs in MLX float32).  8 x 256 view model only.  The mode is

@@ -282,9 +282,13 @@ extern __shared__ __attribute__((aligned(16))) char ring_smem[];
 
 // RING_GROUP = fragments per software-pipeline group (one group in use, one in flight); TOTAL = fragments
 // consumed per pass (multiple of RING_GROUP)
-template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8>
+// CHUNK / STAGES: fragments per ring stage and stages (default 32 x 4 = 128 KiB for one 8-wave workgroup per CU; 16 x 4 =
+// 64 KiB lets two independent 4-wave workgroups share a CU, see mlp_fwd_ring_kernel)
+template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES>
 struct RingW {
-  static constexpr int DPW = RING_CHUNK / NW;          // DMAs per wave per chunk
+  static constexpr int DPW = CHUNK / NW;               // DMAs per wave per chunk
+  static constexpr int STAGE_BYTES = CHUNK * 1024, BIAS_OFF = STAGES * STAGE_BYTES, LDS_BYTES = BIAS_OFF + 2560 * 4;
+  static_assert(DPW * NW == CHUNK && (DPW == 4 || DPW == 8), "ring: 4 or 8 DMAs per wave per chunk");
   const char* __restrict__ wsrc;       // global stream base (uniform)
   unsigned lane16;                     // 16 * lane
   unsigned lds0;                       // LDS byte address of ring_smem (M0 values are absolute)
@@ -297,7 +301,7 @@ struct RingW {
   // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k
   __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
     const int i = wv + NW * k;
-    dma_frag_s(wsrc + ((int64_t)chunk * RING_CHUNK + i) * 1024, lane16, lds0 + stage * RING_STAGE_BYTES + i * 1024);
+    dma_frag_s(wsrc + ((int64_t)chunk * CHUNK + i) * 1024, lane16, lds0 + stage * STAGE_BYTES + i * 1024);
   }
   __device__ __forceinline__ void issue(int chunk, int stage) {
 #pragma unroll
@@ -306,9 +310,9 @@ struct RingW {
   // Whole chunks refill their freed stage one DMA per quarter of the interval (a burst of 4 right behind the barrier
   // stalls both waves of a SIMD on the VMEM issue path at once); the partial last chunk of a pass keeps the burst.
   // (not in the activation-storing training forward, RING_GROUP 2: it is at the VGPR limit and HBM-bound anyway)
-  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && RING_GROUP == 4 && (c + 1) * RING_CHUNK <= TOTAL; }
+  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && RING_GROUP == 4 && (c + 1) * CHUNK <= TOTAL; }
   __device__ __forceinline__ void boundary(int c, int lane) {
-    ring_pos = (ring_pos + 1) & (RING_STAGES - 1);
+    ring_pos = (ring_pos + 1) & (STAGES - 1);
 #if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
 #else
@@ -336,23 +340,23 @@ struct RingW {
     st_h2 = st_h1; st_h1 = st_cur; st_cur = 0;
 #endif
 #if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
-    if (spread(c)) issue_one((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1), 0);
-    else issue((c + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1));
+    if (spread(c)) issue_one((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), 0);
+    else issue((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1));
 #endif
-    woff = ring_pos * RING_STAGE_BYTES + 16 * lane;
+    woff = ring_pos * STAGE_BYTES + 16 * lane;
   }
   // fetch the group that starts at fragment fn (fn % RING_GROUP == 0) into nxt; crossing into a new chunk first
   // runs the ring protocol for it (the previous chunk's last group is already in registers)
   __device__ __forceinline__ void prefetch(int fn, int lane) {
-    if ((fn % RING_CHUNK) == 0) boundary(fn / RING_CHUNK, lane);
+    if ((fn % CHUNK) == 0) boundary(fn / CHUNK, lane);
 #if NERF_ABLATE != 2
-    else if ((fn % (RING_CHUNK / DPW)) == 0 && spread(fn / RING_CHUNK))
-      issue_one((fn / RING_CHUNK + RING_STAGES - 1) % NCHUNK, (ring_pos + RING_STAGES - 1) & (RING_STAGES - 1),
-                (fn % RING_CHUNK) / (RING_CHUNK / DPW));
+    else if ((fn % (CHUNK / DPW)) == 0 && spread(fn / CHUNK))
+      issue_one((fn / CHUNK + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1),
+                (fn % CHUNK) / (CHUNK / DPW));
 #endif
 #pragma unroll
     for (int i = 0; i < RING_GROUP; ++i)
-      nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % RING_CHUNK) * 1024);
+      nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % CHUNK) * 1024);
   }
   __device__ __forceinline__ void note_stores(int k) { st_cur += k; }
   // The counters restart at every pass (conservative: the first boundaries of a pass wait as if no store were in
@@ -365,11 +369,11 @@ struct RingW {
     asm volatile("" : "+s"(wsrc));
   }
   __device__ __forceinline__ void start(int lane) {
-    ring_pos = RING_STAGES - 1;
+    ring_pos = STAGES - 1;
     woff = 0;
     st_cur = st_h1 = st_h2 = 0;
 #pragma unroll
-    for (int c = 0; c < RING_STAGES - 1; ++c) issue(c, c);
+    for (int c = 0; c < STAGES - 1; ++c) issue(c, c);
     prefetch(0, lane);
   }
   __device__ __forceinline__ bf16x8 frag(int f, int lane) {
@@ -382,13 +386,13 @@ struct RingW {
     return cur[f % RING_GROUP];
   }
   __device__ __forceinline__ float4 bias4(int slot) {
-    return *reinterpret_cast<const float4*>(ring_smem + RING_BIAS_OFF + slot * 4);
+    return *reinterpret_cast<const float4*>(ring_smem + BIAS_OFF + slot * 4);
   }
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 template <class WS> struct is_ring { static constexpr bool value = false; };
-template <int N, int T, int G, int W> struct is_ring<RingW<N, T, G, W>> { static constexpr bool value = true; };
+template <int N, int T, int G, int W, int C, int S> struct is_ring<RingW<N, T, G, W, C, S>> { static constexpr bool value = true; };
 
 template <class WS>
 __device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }
@@ -724,14 +728,16 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs
   fwd_tiles<ST, MODE, STORE>(a, ws, tile0, ntiles, lane);
 }
 
-__device__ __forceinline__ void ring_load_bias(const float* __restrict__ bias, int count) {
+__device__ __forceinline__ void ring_load_bias(const float* __restrict__ bias, int count, int bias_off = RING_BIAS_OFF) {
   for (int i = threadIdx.x; i < count; i += blockDim.x)
-    *reinterpret_cast<float*>(ring_smem + RING_BIAS_OFF + 4 * i) = bias[i];
+    *reinterpret_cast<float*>(ring_smem + bias_off + 4 * i) = bias[i];
 }
 
 // variant 3: persistent workgroups of 8 waves x 32 samples, weights through the shared LDS ring
 constexpr int F_CHUNKS = L::F_TOTAL / RING_CHUNK;     // 37
 static_assert(F_CHUNKS * RING_CHUNK == L::F_TOTAL, "forward stream must be whole chunks");
+constexpr int SPLIT_NW = 4, SPLIT_CHUNK = 16;         // the two-workgroups-per-CU form of the training kernels
+constexpr int SPLIT_LDS_BYTES = RING_STAGES * SPLIT_CHUNK * 1024 + 2560 * 4;      // 75 776 B: two fit the 160 KiB of a CU
 
 #ifdef NERF_CLOCK_STAMP
 // Diagnostic build only (tools/probe_clock.py): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
@@ -746,26 +752,33 @@ __device__ unsigned long long g_stamps[4096][4];
 #define NERF_STAMP_PASS()
 #define NERF_STAMP_END()
 #endif
-template <int MODE, bool STORE>
-__global__ void __launch_bounds__(512, 2) mlp_fwd_ring_kernel(FwdArgs a) {
+// NW = 8, CHUNK = 32: ONE persistent workgroup of 8 waves per CU behind one 128 KiB ring (all 8 waves in lockstep).
+// NW = 4, CHUNK = 16: TWO independent workgroups of 4 waves per CU, each behind its own 64 KiB ring: the two waves of a
+// SIMD then belong to different workgroups and are not tied to one ring barrier, so the fragment stores of one group
+// (the CU's store path takes ~29 cycles per KiB, and a wave blocked on a store issues no MFMA) can run under the MFMAs
+// of the other; the price is each group streaming the whole weight image for 128 instead of 256 samples.
+template <int MODE, bool STORE, int NW = 8, int CHUNK = RING_CHUNK>
+__global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_ring_kernel(FwdArgs a) {
+  static_assert(L::F_TOTAL % CHUNK == 0, "forward stream must be whole chunks");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ntiles = (a.M + 31) >> 5;
-  const int64_t nsuper = (ntiles + 7) >> 3;
-  RingW<F_CHUNKS, L::F_TOTAL, (STORE ? 2 : 4)> ws;
+  const int64_t nsuper = (ntiles + NW - 1) / NW;
+  typedef RingW<L::F_TOTAL / CHUNK, L::F_TOTAL, (STORE ? 2 : 4), NW, CHUNK> Ring;
+  Ring ws;
   ws.wsrc = reinterpret_cast<const char*>(a.wf);
   ws.lane16 = 16 * lane;
   ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
   ws.wv = wv;
   ws.start(lane);
-  ring_load_bias(a.bias, L::BI_TOTAL);
+  ring_load_bias(a.bias, L::BI_TOTAL, Ring::BIAS_OFF);
   __syncthreads();
   NERF_STAMP_BEGIN();
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int ln = lane;
     asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
     ws.new_pass();
-    fwd_tiles<1, MODE, STORE>(a, ws, sp * 8 + wv, ntiles, ln);
+    fwd_tiles<1, MODE, STORE>(a, ws, sp * NW + wv, ntiles, ln);
     NERF_STAMP_PASS();
   }
   NERF_STAMP_END();
@@ -1299,14 +1312,15 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_bwd_kernel(BwdArgs
   bwd_tiles<ST>(a, ws, tile0, ntiles, lane);
 }
 
-// the transposed stream is padded with zero fragments to whole chunks (1100 -> 1120)
-constexpr int B_CHUNKS = (L::B_TOTAL + RING_CHUNK - 1) / RING_CHUNK;     // 35
-__global__ void __launch_bounds__(512, 2) mlp_bwd_ring_kernel(BwdArgs a) {
+// the transposed stream is padded with zero fragments to whole chunks (1100 -> 1120 = 35 x 32 = 70 x 16)
+template <int NW = 8, int CHUNK = RING_CHUNK>
+__global__ void __launch_bounds__(64 * NW, 2) mlp_bwd_ring_kernel(BwdArgs a) {
+  static_assert(L::B_PADDED % CHUNK == 0, "padded backward stream must be whole chunks");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t ntiles = (a.M + 31) >> 5;
-  const int64_t nsuper = (ntiles + 7) >> 3;
-  RingW<B_CHUNKS, L::B_TOTAL> ws;
+  const int64_t nsuper = (ntiles + NW - 1) / NW;
+  RingW<(L::B_TOTAL + CHUNK - 1) / CHUNK, L::B_TOTAL, 4, NW, CHUNK> ws;
   ws.wsrc = reinterpret_cast<const char*>(a.wb);
   ws.lane16 = 16 * lane;
   ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
@@ -1316,9 +1330,9 @@ __global__ void __launch_bounds__(512, 2) mlp_bwd_ring_kernel(BwdArgs a) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     ws.new_pass();
-    bwd_tiles<1>(a, ws, sp * 8 + wv, ntiles, ln);
-    // the pass ends inside the last chunk (1100 = 34 * 32 + 12): nothing else to do, the next pass starts at a
-    // chunk boundary again because fragment indices restart at 0
+    bwd_tiles<1>(a, ws, sp * NW + wv, ntiles, ln);
+    // the pass ends inside the last chunk (1100 is not a multiple of the chunk): nothing else to do, the next pass starts
+    // at a chunk boundary again because fragment indices restart at 0
   }
   ws.drain();
 }
@@ -2015,6 +2029,7 @@ static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad
 static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: LDS ring, 8 waves x 32 samples, 32x32x16 MFMA,
                                 // 4: ring, 16x16x32 MFMA, 8 waves x 32 samples (inference only), 5: same, 4 waves x 64 samples
 static int g_ring_wgs = 0;       // persistent workgroups of the ring kernels; 0 = one per CU of the current device
+static int g_ring_split = 1;     // training ring kernels: 1 = one 8-wave workgroup per CU (128 KiB ring), 2 = two 4-wave workgroups (64 KiB rings)
 static int g_mlp_precision = 16; // 16: bf16 MFMA operands, fp32 accumulate (benchmarked mode); 32: fp32 reference-precision mode (mlp32.hip)
 // Packed images whose fp32 streams are current (nerf_mlp_pack builds them only in fp32 mode; a launch in fp32 mode on an
 // image packed in bf16 mode must fail loudly instead of running on stale or uninitialised weights).
@@ -2079,6 +2094,11 @@ using namespace nerf;
 extern "C" int nerf_set_option(const char* key, int value) {
   NERF_REQUIRE(key, NERF_E_NULL, "nerf_set_option: key is NULL");
   if (!strcmp(key, "mlp_variant")) { g_mlp_variant = value; return NERF_OK; }
+  if (!strcmp(key, "ring_split")) {
+    NERF_REQUIRE(value == 1 || value == 2, NERF_E_UNSUPPORTED, "nerf_set_option: ring_split must be 1 or 2");
+    g_ring_split = value;
+    return NERF_OK;
+  }
   if (!strcmp(key, "mlp_precision")) {
     NERF_REQUIRE(value == 16 || value == 32, NERF_E_UNSUPPORTED, "nerf_set_option: mlp_precision must be 16 (bf16 MFMA) or 32 (fp32 MFMA)");
     g_mlp_precision = value;
@@ -2098,6 +2118,7 @@ extern "C" int nerf_get_option(const char* key) {
   if (!strcmp(key, "mlp_variant")) return g_mlp_variant;
   if (!strcmp(key, "mlp_precision")) return g_mlp_precision;
   if (!strcmp(key, "ring_workgroups")) return g_ring_wgs;
+  if (!strcmp(key, "ring_split")) return g_ring_split;
   if (!strcmp(key, "dw_workgroups")) return g_dw_wgs;
   return -1;
 }
@@ -2202,6 +2223,15 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
     return check_launch("mlp forward (ring, 16x16x32)");
   }
   if (variant >= 3 && MODE == 1) {
+    if (acts && g_ring_split == 2) {                      // two 4-wave workgroups per CU, each with its own 64 KiB ring
+      const int64_t nsuper = (ntiles + SPLIT_NW - 1) / SPLIT_NW;
+      const int64_t wgs = 2 * (int64_t)ring_wgs();
+      static DevOnce once2;
+      if (once2.first()) ensure_lds(mlp_fwd_ring_kernel<1, true, SPLIT_NW, SPLIT_CHUNK>, SPLIT_LDS_BYTES);
+      hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, true, SPLIT_NW, SPLIT_CHUNK>), dim3((unsigned)(nsuper < wgs ? nsuper : wgs)),
+                         dim3(64 * SPLIT_NW), SPLIT_LDS_BYTES, s, a);
+      return check_launch("mlp forward (ring, 2 workgroups per CU)");
+    }
     const int64_t nsuper = (ntiles + 7) / 8;
     const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), b(512);
     static DevOnce once;
@@ -2430,12 +2460,20 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz; b.astride = astride16(); b.zstride = zstride16();
   const int variant = g_mlp_variant == 0 ? 3 : g_mlp_variant;
   if (variant >= 3) {
-    const int64_t nsuper = (ntiles + 7) / 8;
-    static DevOnce once;
-    if (once.first()) ensure_lds(mlp_bwd_ring_kernel, RING_LDS_BYTES);
-    if (g_bwd_stage != 2)
-      hipLaunchKernelGGL(mlp_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
+    if (g_bwd_stage != 2 && g_ring_split == 2) {
+      const int64_t nsuper = (ntiles + SPLIT_NW - 1) / SPLIT_NW;
+      const int64_t wgs = 2 * (int64_t)ring_wgs();
+      static DevOnce once2;
+      if (once2.first()) ensure_lds(mlp_bwd_ring_kernel<SPLIT_NW, SPLIT_CHUNK>, SPLIT_LDS_BYTES);
+      hipLaunchKernelGGL((mlp_bwd_ring_kernel<SPLIT_NW, SPLIT_CHUNK>), dim3((unsigned)(nsuper < wgs ? nsuper : wgs)),
+                         dim3(64 * SPLIT_NW), SPLIT_LDS_BYTES, s, b);
+    } else if (g_bwd_stage != 2) {
+      const int64_t nsuper = (ntiles + 7) / 8;
+      static DevOnce once;
+      if (once.first()) ensure_lds(mlp_bwd_ring_kernel<>, RING_LDS_BYTES);
+      hipLaunchKernelGGL(mlp_bwd_ring_kernel<>, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
                          RING_LDS_BYTES, s, b);
+    }
   } else {
     const int st = variant == 2 ? 2 : 1;
     const int64_t blocks = (ntiles + 4 * st - 1) / (4 * st);
