@@ -218,6 +218,28 @@ def test_fp32_mode_backward_and_training_step():
                 a, b = grads[off:off + cnt], fl.grad[off:off + cnt]
                 assert _rel_l2(a, b) < 1e-3 and _relmax(a, b) < 1e-2, (name, part, _rel_l2(a, b), _relmax(a, b))
                 off += cnt
+        # every stored layer (float32 [tile][row][32] stores decoded by nerf_mlp_debug_read) against the oracle's taps:
+        # activations to 1e-4 of the layer's scale, dZ to 1e-3 rel-L2 (a handful of units flip at |z| ~ 1e-7)
+        from nerf_meets_mlx_amd.models.NeRF import debug_layer
+        fl2 = flat.clone().requires_grad_(True)
+        taps = {}
+        out2 = O.run_model(arch, O.unflatten_params(arch, fl2), pos, vd, taps=taps)
+        for t in taps.values():
+            t.retain_grad()
+        (out2 * g).sum().backward()
+        for li, name in enumerate(LAYER_NAMES):
+            act = debug_layer(m, "acts", li).cpu()
+            assert act.shape == taps[name].shape and _relmax(act, taps[name].detach()) < 1e-4, (name, _relmax(act, taps[name].detach()))
+            dz = debug_layer(m, "dz", li).cpu()
+            ref = taps[name].grad if name == "feature" else taps[name].grad * (taps[name].detach() > 0).float()
+            assert _rel_l2(dz, ref) < 1e-3, (name, _rel_l2(dz, ref))
+        pe = debug_layer(m, "acts", 10).cpu()
+        xe = O.embed(pos, vd)
+        assert float((pe[:, :63] - xe[:, :63]).abs().max()) < 2e-6 and float(pe[:, 63].abs().max()) == 0.0
+        # NeRF.forward(x) on embedded rows takes the same fp32 kernels
+        rows = torch.randn(100, 90, generator=torch.Generator().manual_seed(3))
+        got = m.forward(rows.to(DEV)).cpu()
+        assert _relmax(got, O.nerf_forward(arch, O.unflatten_params(arch, flat), rows)) < 1e-4
         H = W = 24
         imgs, poses, _, _, K = synthetic.make_dataset(H, W, 3, seed=0, device=DEV)
         tr = Trainer(imgs, poses, K, N_rand=128, n_depth_samples=64, N_importance=128, seed=4, device=DEV)
@@ -444,6 +466,26 @@ def test_stale_activation_and_stale_weight_guards():
         m2.parameters()["rgb_linear"]["bias"].add_(1.0)
     after = m2.query(rays, z)
     assert float((after[..., :3] - before[..., :3] - 1.0).abs().max()) < 2e-2 and torch.equal(after[..., 3], before[..., 3])
+    # option validation and the refusals of the new entry points
+    from nerf_meets_mlx_amd import _native as NV, sampling
+    L = NV.lib()
+    assert L.nerf_set_option(b"mlp_precision", 8) == -3 and L.nerf_set_option(b"ring_split", 3) == -3
+    assert L.nerf_get_option(b"mlp_precision") == 16 and L.nerf_get_option(b"ring_split") == 1
+    zz = torch.rand(4, 8, device=DEV)
+    assert L.nerf_add_noise_z(NV.ptr(zz), NV.ptr(zz), 4, 8, 1.0, NV.ptr(zz), None) == -2        # in place is refused
+    # a launch in fp32 mode on a weight image that was packed in bf16 mode fails loudly instead of using stale streams
+    import ctypes as C
+    m3, _, _ = _model_pair(6)
+    packed = m3.packed()                                   # packed with mlp_precision == 16
+    L.nerf_set_option(b"mlp_precision", 32)
+    try:
+        out = torch.empty(8, 64, 4, device=DEV)
+        rc = L.nerf_query_fused(C.byref(m3.arch), NV.ptr(packed), NV.ptr(rays), NV.ptr(z), 8, 64, 0, NV.ptr(out), None, NV.stream())
+        assert rc == -3 and b"packed" in L.nerf_last_error()
+        ok = m3.query(rays, z)                             # the host mirror re-packs when the mode changed
+        assert torch.isfinite(ok).all()
+    finally:
+        L.nerf_set_option(b"mlp_precision", 16)
     # gather_rows: out-of-range indices never read, they give NaN rows
     src = torch.arange(12, dtype=torch.float32, device=DEV).reshape(4, 3)
     got = index.gather_rows(src, torch.tensor([0, 3, 4, -1], device=DEV))
