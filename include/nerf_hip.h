@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 1
+/* 2 (round 2): nerf_mlp_packed_bytes / nerf_mlp_dz_bytes return larger sizes (fp32 weight streams behind the bf16 image;
+ * split-K partial tiles behind the dZ blocks) and nerf_mlp_acts_bytes / _dz_bytes depend on "mlp_precision": callers that
+ * always size their buffers with these functions are unaffected; new entry points were only added.                  */
+#define NERF_ABI_VERSION 2
 
 #define NERF_OK 0
 #define NERF_E_NULL (-1)        /* required pointer is NULL                        */

@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _need_gpu():
     assert torch.cuda.is_available(), "GPU tests need a ROCm device"
     from nerf_meets_mlx_amd import _native
-    assert _native.lib().nerf_abi_version() == 1
+    assert _native.lib().nerf_abi_version() == 2
 
 
 def _relmax(a, b):

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in nerf_hip.h but not exported"
         assert s in _native.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_native.SIGNATURES) == set(syms)
-    assert lib.nerf_abi_version() == 1                       # host-only call, no GPU needed
+    assert lib.nerf_abi_version() == 2                       # host-only call, no GPU needed
 
 
 def test_host_argument_validation_without_gpu():
