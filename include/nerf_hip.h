@@ -151,6 +151,14 @@ int nerf_composite_backward(const float* raw, const float* z, const float* rays,
 int nerf_mse_loss_grad(const float* pred, const float* target, int64_t count, float grad_scale, float* loss_out,
                        float* d_pred, void* stream);
 
+/* replaces, for the training step, the three calls above as ONE pass per ray: what nn.value_and_grad differentiates
+ * in entrypoints/__test_nerf.py:47-126 -- raw2outputs (raw_noise_std = 0 there: SURVEY Q5), loss = mean((rgb - target)^2)
+ * over B x 3, d_raw = d loss / d raw x grad_scale.  loss_out[0] += loss (caller zeroes it); rgb (optional): [B,3].
+ * rgb and d_raw are bit-identical to nerf_composite_forward + nerf_mse_loss_grad + nerf_composite_backward.        */
+int nerf_composite_mse_backward(const float* raw, const float* z, const float* rays, int64_t B, int n, int white_bkgd,
+                                const float* target, float grad_scale, float* loss_out, float* rgb, float* d_raw,
+                                void* stream);
+
 /* replaces: ops/metric.py:20-64 SSIM (unfinished upstream: the body stops after the five windowed moments; this is
  * the formula those moments feed).  pred, gt: [N,C,H,W] float32 device; window_host: the 1-D window (w_size <= 33
  * taps, the 2-D window of create_window :49-55 is its outer product), applied as a depthwise VALID convolution

@@ -34,6 +34,7 @@ SIGNATURES = {
     "nerf_composite_forward": (_I, [_P, _P, _P, _I64, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P]),
     "nerf_composite_backward": (_I, [_P, _P, _P, _I64, _I, _F, _P, _I, _P, _P, _P, _P, _P]),
     "nerf_mse_loss_grad": (_I, [_P, _P, _I64, _F, _P, _P, _P]),
+    "nerf_composite_mse_backward": (_I, [_P, _P, _P, _I64, _I, _I, _P, _F, _P, _P, _P, _P]),
     "nerf_ssim_sums": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _F, _F, _P, _P]),
     "nerf_mlp_param_count": (_I64, [_P]),
     "nerf_mlp_packed_bytes": (_I64, [_P]),

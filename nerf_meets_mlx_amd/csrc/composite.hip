@@ -128,6 +128,65 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   }
 }
 
+// Training form: raw2outputs -> MSE against the target pixel -> d loss / d raw in ONE pass per ray (what
+// nn.value_and_grad differentiates in entrypoints/__test_nerf.py:47-126).  The backward kernel recomputes the forward
+// quantities of the ray anyway, so the colour, its residual and the upstream gradient 2 (rgb - y) / (3 B) cost one
+// wave reduction more; two launches and one pass over raw fewer than forward + mse + backward.  rgb and d_raw are
+// bit-identical to the staged kernels (same operations in the same order); the loss is summed in another order.
+template <int CH>
+__global__ void __launch_bounds__(256) composite_train_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                              const float* __restrict__ rays, int64_t B, int n, int white,
+                                                              const float* __restrict__ target, float grad_scale,
+                                                              float* __restrict__ loss, float* __restrict__ rgb_out,
+                                                              float* __restrict__ d_raw) {
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float inv = 1.0f / (float)(B * 3);
+  float sq = 0.0f;
+  for (int64_t ray = blockIdx.x * 4 + wv; ray < B; ray += (int64_t)gridDim.x * 4) {
+    const float* rr = rays + ray * NERF_RAY_STRIDE;
+    const float dnorm = sqrtf(rr[3] * rr[3] + rr[4] * rr[4] + rr[5] * rr[5]);
+    RayQ q[CH];
+    composite_lane<CH>(raw + ray * n * 4, z + ray * n, nullptr, 0.0f, dnorm, n, lane, q);
+    float sr = 0, sg = 0, sb = 0, sa = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { sr += q[c].w * q[c].r; sg += q[c].w * q[c].g; sb += q[c].w * q[c].b; sa += q[c].w; }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sa = wave_sum(sa);
+    if (white) { sr = sr + (1.0f - sa); sg = sg + (1.0f - sa); sb = sb + (1.0f - sa); }          // render.py:91-92
+    const float er = sr - target[ray * 3], eg = sg - target[ray * 3 + 1], eb = sb - target[ray * 3 + 2];
+    if (lane == 0) {
+      sq += er * er; sq += eg * eg; sq += eb * eb;
+      if (rgb_out) { rgb_out[ray * 3] = sr; rgb_out[ray * 3 + 1] = sg; rgb_out[ray * 3 + 2] = sb; }
+    }
+    const float gr = grad_scale * 2.0f * er * inv, gg = grad_scale * 2.0f * eg * inv, gb = grad_scale * 2.0f * eb * inv;
+    const float gacc = 0.0f - (white ? (gr + gg + gb) : 0.0f);
+    float G[CH], gw[CH];
+    float run = 0.0f;
+#pragma unroll
+    for (int c = CH - 1; c >= 0; --c) {
+      G[c] = gr * q[c].r + gg * q[c].g + gb * q[c].b + gacc + 0.0f * q[c].z;
+      gw[c] = run;
+      run += G[c] * q[c].w;
+    }
+    const float incl = wave_rscan_incl(run, lane);
+    const float after = incl - run;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k = lane * CH + c;
+      if (k >= n) continue;
+      const float suffix = (k < n - 1) ? (after + gw[c]) : 0.0f;
+      const float da = (q[c].x > 0.0f) ? G[c] * q[c].T * expf(-q[c].x) : 0.0f;
+      const float dx = da - suffix;
+      float4 o;
+      o.x = q[c].w * gr; o.y = q[c].w * gg; o.z = q[c].w * gb; o.w = q[c].delta * dx;
+      *reinterpret_cast<float4*>(d_raw + (ray * n + k) * 4) = o;
+    }
+  }
+  if (lane == 0) part[wv] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv);
+}
+
 __global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ p, const float* __restrict__ t,
                                                   int64_t count, float grad_scale, float* __restrict__ loss,
                                                   float* __restrict__ d_pred) {
@@ -186,6 +245,20 @@ extern "C" int nerf_composite_backward(const float* raw, const float* z, const f
   DISPATCH_CH(n, CALL);
 #undef CALL
   return check_launch("nerf_composite_backward");
+}
+
+extern "C" int nerf_composite_mse_backward(const float* raw, const float* z, const float* rays, int64_t B, int n,
+                                          int white_bkgd, const float* target, float grad_scale, float* loss_out,
+                                          float* rgb, float* d_raw, void* stream) {
+  NERF_REQUIRE(n >= 1 && n <= 1024, NERF_E_SHAPE, "nerf_composite_mse_backward: need 1 <= n <= 1024 (n=%d)", n);
+  if (B <= 0) return NERF_OK;
+  NERF_REQUIRE(raw && z && rays && target && d_raw, NERF_E_NULL, "nerf_composite_mse_backward: NULL pointer");
+  const dim3 g((unsigned)((B + 3) / 4 > 8192 ? 8192 : (B + 3) / 4)), b(256);
+  auto st = as_stream(stream);
+#define CALL(C) hipLaunchKernelGGL(composite_train_kernel<C>, g, b, 0, st, raw, z, rays, B, n, white_bkgd, target, grad_scale, loss_out, rgb, d_raw)
+  DISPATCH_CH(n, CALL);
+#undef CALL
+  return check_launch("nerf_composite_mse_backward");
 }
 
 extern "C" int nerf_mse_loss_grad(const float* pred, const float* target, int64_t count, float grad_scale,

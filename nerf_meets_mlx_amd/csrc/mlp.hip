@@ -151,9 +151,9 @@ __device__ float bwd_src(const float* __restrict__ p, int f, int r, int h, int j
   return p[L::pw(l) + nn * 256 + row];
 }
 
-__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ p, bf16x8* __restrict__ wf,
-                                                   bf16x8* __restrict__ wb, float* __restrict__ bias) {
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+constexpr int PACK_THREADS = (L::F_TOTAL + L::B_PADDED) * 64 + L::BI_TOTAL;      // one thread per 16-byte lane slot / bias
+__device__ __forceinline__ void pack_part(int tid, const float* __restrict__ p, bf16x8* __restrict__ wf,
+                                          bf16x8* __restrict__ wb, float* __restrict__ bias) {
   const int nf = L::F_TOTAL * 64, nb = L::B_PADDED * 64;
   if (tid < nf + nb) {
     const bool fw = tid < nf;
@@ -849,8 +849,18 @@ __device__ float fwd_src16(const float* __restrict__ p, int f, int i, int g, int
   return 0.0f;
 }
 
-__global__ void __launch_bounds__(256) pack16_kernel(const float* __restrict__ p, bf16x8* __restrict__ w16) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+// the whole bf16 image in ONE launch (was two: at N_rand = 1024 the ~30 five-microsecond launches of an iteration are a tenth
+// of it): blocks [0, PACK_BLOCKS) build the 32x32x16 forward / backward streams and the bias slots, the rest the 16x16x32
+// forward stream of the render kernels
+constexpr int PACK_BLOCKS = (PACK_THREADS + 255) / 256, PACK16_BLOCKS = L::F16_PADDED * 64 / 256;
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ p, bf16x8* __restrict__ wf,
+                                                   bf16x8* __restrict__ wb, float* __restrict__ bias,
+                                                   bf16x8* __restrict__ w16) {
+  if (blockIdx.x < PACK_BLOCKS) {
+    pack_part(blockIdx.x * 256 + threadIdx.x, p, wf, wb, bias);
+    return;
+  }
+  const int t = (blockIdx.x - PACK_BLOCKS) * 256 + threadIdx.x;
   if (t >= L::F16_PADDED * 64) return;
   const int f = t >> 6, lane = t & 63;
   bf16x8 v;
@@ -2175,9 +2185,7 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
   bf16x8* wf = reinterpret_cast<bf16x8*>(base);
   bf16x8* wb = reinterpret_cast<bf16x8*>(base + (size_t)L::F_TOTAL * 1024);
   float* bias = reinterpret_cast<float*>(base + (size_t)(L::F_TOTAL + L::B_PADDED) * 1024);
-  const int total = (L::F_TOTAL + L::B_PADDED) * 64 + L::BI_TOTAL;
-  hipLaunchKernelGGL(pack_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), params, wf, wb, bias);
-  hipLaunchKernelGGL(pack16_kernel, dim3(L::F16_PADDED * 64 / 256), dim3(256), 0, as_stream(stream), params,
+  hipLaunchKernelGGL(pack_kernel, dim3(PACK_BLOCKS + PACK16_BLOCKS), dim3(256), 0, as_stream(stream), params, wf, wb, bias,
                      reinterpret_cast<bf16x8*>(base + L::F16_OFFSET));
   int rc = check_launch("nerf_mlp_pack");
   if (rc) return rc;

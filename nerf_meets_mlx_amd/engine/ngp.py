@@ -8,7 +8,7 @@ channel_input_views=16, list_skip_connection_layers=[], is_use_view_directions=T
 trained by the coarse-only loop of `render_rays` (rendering/render.py:112-162) + `raw2outputs` + MSE + Adam.
 
 Device work: nerf_hashgrid_forward / nerf_sh_encode -> nerf_mlp_forward_train (2 x 64 kernels) ->
-nerf_composite_forward -> nerf_mse_loss_grad -> nerf_composite_backward -> nerf_mlp_backward_inputs (dZ chain, dW,
+nerf_composite_mse_backward (raw2outputs + MSE + adjoint, one launch) -> nerf_mlp_backward_inputs (dZ chain, dW,
 dL/dfeatures) -> nerf_hashgrid_backward (float atomics) -> nerf_adam_step x 2.  torch only concatenates the two
 feature blocks and forms o + z d.
 """
@@ -23,7 +23,6 @@ from .. import parallel, sampling
 from ..encoding.multi_hash import MultiHashEncoding
 from ..encoding.spherical_harmonics import SphericalHarmonicsEncoding
 from ..models.NeRF import Adam, NeRF
-from ..ops.metric import mse_loss_grad
 from ..rendering import render
 from .trainer import Trainer
 
@@ -157,9 +156,7 @@ class NGPTrainer(Trainer):
         self.opt.learning_rate = self.lrate * (0.1 ** (self.it / (self.lrate_decay * 1000)))
         z = sampling.sample_coarse(rays, self.n)
         raw = self.field.query(rays, z, train=True)
-        rgb, _, _, _, _ = render.composite(raw, z, rays, 0.0, self.white_bkgd)
-        loss, d_rgb = mse_loss_grad(rgb, target)
-        d_raw = render.composite_backward(raw, z, rays, d_rgb, self.white_bkgd)
+        loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, self.white_bkgd)
         g_mlp, g_tab = self.field.backward(d_raw)
         parallel.allreduce_sum_(g_mlp)
         parallel.allreduce_sum_(g_tab.view(-1))

@@ -23,7 +23,6 @@ import torch
 from .. import parallel, sampling
 from ..models.NeRF import Adam, NeRF
 from ..ops import index
-from ..ops.metric import mse_loss_grad
 from ..rendering import ray, render
 
 
@@ -59,9 +58,7 @@ class Trainer:
     # ---------------------------------------------------------------- one network step
     def _step_net(self, model: NeRF, rays, z, target, white: bool):
         raw = model.query(rays, z, ref_quirks=self.q, train=True)
-        rgb, _, _, weights, _ = render.composite(raw, z, rays, 0.0, white)
-        loss, d_rgb = mse_loss_grad(rgb, target)
-        d_raw = render.composite_backward(raw, z, rays, d_rgb, white)
+        loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, white)      # raw2outputs + MSE + adjoint
         grads = model.backward(d_raw)
         parallel.allreduce_sum_(grads)                                         # C1: the only collective
         self.opt.update(model, grads, grad_scale=1.0 / self.world)

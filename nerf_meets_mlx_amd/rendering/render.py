@@ -44,6 +44,19 @@ def composite_backward(raw, z_vals, rays, d_rgb, white_bkgd=False, d_acc=None, d
     return d_raw
 
 
+def composite_mse_backward(raw, z_vals, rays, target, white_bkgd=False, grad_scale: float = 1.0, need_rgb: bool = False):
+    """(loss [1], d_raw [B,n,4], rgb [B,3] or None): raw2outputs + MSE + their gradient w.r.t. raw in one launch
+    (`nerf_composite_mse_backward`); same values as composite + mse_loss_grad + composite_backward."""
+    B, n = z_vals.shape
+    loss = torch.zeros(1, dtype=torch.float32, device=raw.device)
+    d_raw = torch.empty(B, n, 4, dtype=torch.float32, device=raw.device)
+    rgb = torch.empty(B, 3, dtype=torch.float32, device=raw.device) if need_rgb else None
+    N.check(N.lib().nerf_composite_mse_backward(N.ptr(raw), N.ptr(z_vals), N.ptr(rays), B, n, int(bool(white_bkgd)),
+                                                N.ptr(N.f32(target)), float(grad_scale), N.ptr(loss), N.ptr(rgb),
+                                                N.ptr(d_raw), N.stream()))
+    return loss, d_raw, rgb
+
+
 _WS = {}
 
 

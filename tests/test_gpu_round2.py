@@ -572,3 +572,33 @@ def test_entrypoint_on_a_blender_dataset_on_disk(tmp_path):
     losses = [l[1] for l in res["losses"]]
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
     assert len(res["frames"]) == 1 and res["frames"][0].shape == (40, 40, 3) and len(res["video"]) == 1
+
+
+# ------------------------------------------------------------------------------ a13 + a20 fused for the training step
+@pytest.mark.parametrize("n,white", [(64, True), (192, False), (7, True), (300, True)])
+def test_composite_mse_backward_equals_the_staged_kernels(n, white):
+    """`nerf_composite_mse_backward` (raw2outputs + MSE + their adjoint in one launch per ray, what the trainers call) is
+    bit-identical in rgb and d_raw to nerf_composite_forward -> nerf_mse_loss_grad -> nerf_composite_backward, and its
+    loss agrees to float32 summation order; against the oracle's autograd the gradient is within 1e-5 relative."""
+    from nerf_meets_mlx_amd.ops.metric import mse_loss_grad
+    from nerf_meets_mlx_amd.rendering import render
+    B = 133
+    g = torch.Generator().manual_seed(n)
+    rays = _rays(B, 5)
+    z = torch.sort(torch.rand(B, n, generator=g) * 4 + 2, -1).values
+    raw = torch.randn(B, n, 4, generator=g)
+    raw[..., 3] = raw[..., 3] * 3.0                                    # signed sigma: the un-ReLU'd transmittance matters (Q10)
+    target = torch.rand(B, 3, generator=g)
+    rd, zd, rwd, td = rays.to(DEV), z.to(DEV), raw.to(DEV), target.to(DEV)
+    rgb, _, _, _, _ = render.composite(rwd, zd, rd, 0.0, white)
+    loss_s, d_rgb = mse_loss_grad(rgb, td)
+    d_raw_s = render.composite_backward(rwd, zd, rd, d_rgb, white)
+    loss_f, d_raw_f, rgb_f = render.composite_mse_backward(rwd, zd, rd, td, white, need_rgb=True)
+    assert torch.equal(rgb_f, rgb) and torch.equal(d_raw_f, d_raw_s)
+    assert abs(float(loss_f) - float(loss_s)) <= 1e-6 * abs(float(loss_s))
+    rw = raw.clone().double().requires_grad_(True)
+    o_rgb, *_ = O.raw2outputs(rw, z.double(), rays[:, 3:6].double(), 0.0, white)
+    O.mse(o_rgb, target.double()).backward()
+    assert _rel_l2(d_raw_f.cpu(), rw.grad) < 1e-5
+    half = render.composite_mse_backward(rwd, zd, rd, td, white, grad_scale=0.5)[1]
+    assert torch.equal(half, 0.5 * d_raw_f)
