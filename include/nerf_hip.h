@@ -65,6 +65,14 @@ int nerf_pixel_permutation(int64_t* out_idx, int64_t n, int64_t domain, uint64_t
 int nerf_ray_gen(const int64_t* pixel_idx, int64_t n, int H, int W, const double* K_host, const float* c2w_host,
                  float near, float far, float* rays, int64_t* coords, void* stream);
 
+/* replaces, for the training step, the three calls around it as ONE launch: entrypoints/__test_nerf.py:213-236 (N_rand
+ * distinct pixels of one image, their rays, their target colours) + :60-82 (ray packing).  Pixel i of the batch is
+ * P(seed; offset + i) of nerf_pixel_permutation over H*W; rays [n,11] as nerf_ray_gen; target [n,3] = image[pixel];
+ * pixel_idx (optional) [n] int64.  image: [H*W,3] float32 device.  Outputs bit-identical to the three separate calls. */
+int nerf_sample_batch(int64_t n, int H, int W, uint64_t seed, uint64_t offset, const double* K_host, const float* c2w_host,
+                      float near, float far, const float* image, float* rays, float* target, int64_t* pixel_idx,
+                      void* stream);
+
 /* out[i, :] = src[idx[i], :]   (target pixel gather, entrypoints/__test_nerf.py:236).
  * idx[i] outside [0, n_src) is never dereferenced: that output row is NaN.               */
 int nerf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t n, int channels, float* out,

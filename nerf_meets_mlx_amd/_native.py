@@ -18,6 +18,7 @@ SIGNATURES = {
     "nerf_last_error": (C.c_char_p, []),
     "nerf_pixel_permutation": (_I, [_P, _I64, _I64, _U64, _U64, _P]),
     "nerf_ray_gen": (_I, [_P, _I64, _I, _I, C.POINTER(C.c_double), C.POINTER(C.c_float), _F, _F, _P, _P, _P]),
+    "nerf_sample_batch": (_I, [_I64, _I, _I, _U64, _U64, C.POINTER(C.c_double), C.POINTER(C.c_float), _F, _F, _P, _P, _P, _P, _P]),
     "nerf_gather_rows": (_I, [_P, _I64, _P, _I64, _I, _P, _P]),
     "nerf_ndc_rays": (_I, [_P, _I64, _I, _I, _F, _F, _P]),
     "nerf_sample_coarse": (_I, [_P, _I64, _I, _I, _F, _P, _P, _P]),

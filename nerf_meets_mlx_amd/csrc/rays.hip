@@ -54,28 +54,47 @@ __global__ void perm_kernel(int64_t* out, int64_t n, uint64_t domain, uint64_t o
 
 struct Cam { double fx, fy, cx, cy; float r[9]; float t[3]; };
 
+__device__ __forceinline__ void write_ray(int64_t i, int64_t p, int W, const Cam& cam, float near, float far,
+                                          float* __restrict__ rays, int64_t* __restrict__ coords) {
+  const int64_t row = p / W, col = p - row * W;
+  // dirs = [(i-cx)/fx, -(j-cy)/fy, -1], i = column, j = row, integer pixel centres
+  const double dx = ((double)col - cam.cx) / cam.fx;
+  const double dy = -((double)row - cam.cy) / cam.fy;
+  const double dz = -1.0;
+  double d[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    d[a] = dx * (double)cam.r[3 * a + 0] + dy * (double)cam.r[3 * a + 1] + dz * (double)cam.r[3 * a + 2];
+  const float fx_ = (float)d[0], fy_ = (float)d[1], fz_ = (float)d[2];
+  // viewdirs = d / |d| on the float32 d (entrypoints/__test_nerf.py:62-64 works on the f32 array)
+  const float inv = 1.0f / sqrtf(fx_ * fx_ + fy_ * fy_ + fz_ * fz_);
+  float* o = rays + i * NERF_RAY_STRIDE;
+  o[0] = cam.t[0]; o[1] = cam.t[1]; o[2] = cam.t[2];
+  o[3] = fx_; o[4] = fy_; o[5] = fz_;
+  o[6] = near; o[7] = far;
+  o[8] = fx_ * inv; o[9] = fy_ * inv; o[10] = fz_ * inv;
+  if (coords) { coords[2 * i] = row; coords[2 * i + 1] = col; }
+}
+
 __global__ void ray_gen_kernel(const int64_t* __restrict__ idx, int64_t n, int W, Cam cam, float near, float far,
                                float* __restrict__ rays, int64_t* __restrict__ coords) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    write_ray(i, idx ? idx[i] : i, W, cam, near, far, rays, coords);
+}
+
+// One training batch in one launch (entrypoints/__test_nerf.py:213-236 + 60-82): the i-th of n distinct pixels of the
+// keyed permutation, its ray, and its target colour from the resident image -- perm_kernel, ray_gen_kernel and
+// gather_rows_kernel back to back, with the same arithmetic (bit-identical outputs), as ONE kernel: at N_rand = 1024 an
+// iteration is ~1.3 ms and each five-microsecond launch shows.
+__global__ void sample_batch_kernel(int64_t n, uint64_t domain, uint64_t offset, PermKey key, int W, Cam cam, float near,
+                                    float far, const float* __restrict__ image, float* __restrict__ rays,
+                                    float* __restrict__ target, int64_t* __restrict__ idx_out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = idx ? idx[i] : i;
-    const int64_t row = p / W, col = p - row * W;
-    // dirs = [(i-cx)/fx, -(j-cy)/fy, -1], i = column, j = row, integer pixel centres
-    const double dx = ((double)col - cam.cx) / cam.fx;
-    const double dy = -((double)row - cam.cy) / cam.fy;
-    const double dz = -1.0;
-    double d[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-      d[a] = dx * (double)cam.r[3 * a + 0] + dy * (double)cam.r[3 * a + 1] + dz * (double)cam.r[3 * a + 2];
-    const float fx_ = (float)d[0], fy_ = (float)d[1], fz_ = (float)d[2];
-    // viewdirs = d / |d| on the float32 d (entrypoints/__test_nerf.py:62-64 works on the f32 array)
-    const float inv = 1.0f / sqrtf(fx_ * fx_ + fy_ * fy_ + fz_ * fz_);
-    float* o = rays + i * NERF_RAY_STRIDE;
-    o[0] = cam.t[0]; o[1] = cam.t[1]; o[2] = cam.t[2];
-    o[3] = fx_; o[4] = fy_; o[5] = fz_;
-    o[6] = near; o[7] = far;
-    o[8] = fx_ * inv; o[9] = fy_ * inv; o[10] = fz_ * inv;
-    if (coords) { coords[2 * i] = row; coords[2 * i + 1] = col; }
+    uint64_t v = offset + (uint64_t)i;
+    do { v = feistel(v, key); } while (v >= domain);
+    write_ray(i, (int64_t)v, W, cam, near, far, rays, nullptr);
+    target[3 * i] = image[3 * v]; target[3 * i + 1] = image[3 * v + 1]; target[3 * i + 2] = image[3 * v + 2];
+    if (idx_out) idx_out[i] = (int64_t)v;
   }
 }
 
@@ -141,6 +160,39 @@ extern "C" int nerf_ray_gen(const int64_t* pixel_idx, int64_t n, int H, int W, c
   hipLaunchKernelGGL(ray_gen_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), pixel_idx, n, W, cam,
                      near, far, rays, coords);
   return check_launch("nerf_ray_gen");
+}
+
+static PermKey make_key(uint64_t seed, uint64_t domain) {
+  int bits = 2;
+  while (bits < 64 && (1ull << bits) < domain) ++bits;
+  if (bits & 1) ++bits;
+  PermKey key;
+  key.half_bits = bits / 2;
+  for (int r = 0; r < 4; ++r) key.k[r] = (uint32_t)splitmix64(seed + (uint64_t)r);
+  return key;
+}
+static Cam make_cam(const double* K, const float* c2w) {
+  Cam cam;
+  cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) cam.r[3 * a + b] = c2w[4 * a + b];
+    cam.t[a] = c2w[4 * a + 3];
+  }
+  return cam;
+}
+
+extern "C" int nerf_sample_batch(int64_t n, int H, int W, uint64_t seed, uint64_t offset, const double* K,
+                                 const float* c2w, float near, float far, const float* image, float* rays,
+                                 float* target, int64_t* pixel_idx, void* stream) {
+  NERF_REQUIRE(H > 0 && W > 0 && n >= 0, NERF_E_SHAPE, "nerf_sample_batch: bad H/W/n");
+  NERF_REQUIRE((int64_t)offset + n <= (int64_t)H * W, NERF_E_SHAPE,
+               "nerf_sample_batch: need offset+n <= H*W (n=%lld H*W=%lld)", (long long)n, (long long)H * W);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(K && c2w && image && rays && target, NERF_E_NULL, "nerf_sample_batch: NULL pointer");
+  const uint64_t domain = (uint64_t)H * (uint64_t)W;
+  hipLaunchKernelGGL(sample_batch_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), n, domain, offset,
+                     make_key(seed, domain), W, make_cam(K, c2w), near, far, image, rays, target, pixel_idx);
+  return check_launch("nerf_sample_batch");
 }
 
 extern "C" int nerf_gather_rows(const float* src, int64_t n_src, const int64_t* idx, int64_t n, int channels,

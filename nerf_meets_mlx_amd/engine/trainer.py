@@ -68,9 +68,9 @@ class Trainer:
         """(rays [B,11], target [B,3]); by default one random image, N_rand distinct pixels."""
         if img_i is None:
             img_i = int(self.rng.integers(0, self.images.shape[0]))            # np.random.choice(i_train)
-        if pixel_idx is None:
-            pixel_idx = index.pixel_permutation(self.N_rand, self.H * self.W,
-                                                parallel.rank_seed(self.seed, self.rank, 3) + self.it, 0, self.device)
+        if pixel_idx is None:                                                  # the usual case: one fused launch
+            return ray.sample_batch(self.H, self.W, self.K, self.poses[img_i, :3, :4], self.near, self.far,
+                                    self.images[img_i], self.N_rand, parallel.rank_seed(self.seed, self.rank, 3) + self.it)
         rays = ray.gen_rays(self.H, self.W, self.K, self.poses[img_i, :3, :4], self.near, self.far, pixel_idx)
         target = index.gather_rows(self.images[img_i].reshape(-1, 3), pixel_idx)
         return rays, target

@@ -35,6 +35,20 @@ def gen_rays(H: int, W: int, K, c2w, near: float, far: float, pixel_idx: Optiona
     return (rays, coords) if return_coords else rays
 
 
+def sample_batch(H: int, W: int, K, c2w, near: float, far: float, image: torch.Tensor, n: int, seed: int, offset: int = 0,
+                 return_idx: bool = False):
+    """One training batch in one launch (`nerf_sample_batch`): n distinct pixels of `image` [H,W,3] (the keyed permutation
+    of ops.index.pixel_permutation), their packed rays [n,11] and target colours [n,3] -- `__test_nerf.py:213-236, 60-82`."""
+    img = N.f32(image).reshape(-1, 3)
+    rays = torch.empty(n, 11, dtype=torch.float32, device=img.device)
+    target = torch.empty(n, 3, dtype=torch.float32, device=img.device)
+    idx = torch.empty(n, dtype=torch.int64, device=img.device) if return_idx else None
+    Kc, cc = _host_cam(K, c2w)
+    N.check(N.lib().nerf_sample_batch(n, H, W, seed & ((1 << 64) - 1), offset, Kc, cc, float(near), float(far), N.ptr(img),
+                                      N.ptr(rays), N.ptr(target), N.ptr(idx), N.stream()))
+    return (rays, target, idx) if return_idx else (rays, target)
+
+
 def get_rays(H: int, W: int, K, c2w, device="cuda"):
     """(rays_o, rays_d), each [H,W,3] float32 (`rendering/ray.py:7-35`)."""
     rays = gen_rays(H, W, K, c2w, 0.0, 1.0, None, device)

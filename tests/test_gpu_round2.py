@@ -602,3 +602,22 @@ def test_composite_mse_backward_equals_the_staged_kernels(n, white):
     assert _rel_l2(d_raw_f.cpu(), rw.grad) < 1e-5
     half = render.composite_mse_backward(rwd, zd, rd, td, white, grad_scale=0.5)[1]
     assert torch.equal(half, 0.5 * d_raw_f)
+
+
+def test_sample_batch_equals_permutation_raygen_gather():
+    """`nerf_sample_batch` (pixel permutation + ray generation + target gather in one launch) is bit-identical to the
+    three separate entry points, integer pixel indices included (the contract's "bit-exact ray/pixel indices")."""
+    from nerf_meets_mlx_amd.ops import index
+    from nerf_meets_mlx_amd.rendering import ray
+    H, W = 37, 53
+    K = np.array([[60.0, 0, W / 2], [0, 61.0, H / 2], [0, 0, 1]])
+    c2w = O.pose_spherical(70.0, -25.0, 4.0)[:3, :4]
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(0)).to(DEV)
+    for n, seed, off in [(1024, 12345, 0), (H * W, 7, 0), (5, 99, 100)]:
+        rays, target, idx = ray.sample_batch(H, W, K, c2w, 2.0, 6.0, img, n, seed, off, return_idx=True)
+        want_idx = index.pixel_permutation(n, H * W, seed, off, DEV)
+        assert torch.equal(idx, want_idx) and len(set(idx.tolist())) == n
+        assert torch.equal(rays, ray.gen_rays(H, W, K, c2w, 2.0, 6.0, want_idx))
+        assert torch.equal(target, index.gather_rows(img.reshape(-1, 3), want_idx))
+    with pytest.raises(ValueError):
+        ray.sample_batch(H, W, K, c2w, 2.0, 6.0, img, H * W + 1, 0)
