@@ -467,7 +467,7 @@ def test_stale_activation_and_stale_weight_guards():
     after = m2.query(rays, z)
     assert float((after[..., :3] - before[..., :3] - 1.0).abs().max()) < 2e-2 and torch.equal(after[..., 3], before[..., 3])
     # option validation and the refusals of the new entry points
-    from nerf_meets_mlx_amd import _native as NV, sampling
+    from nerf_meets_mlx_amd import _native as NV
     L = NV.lib()
     assert L.nerf_set_option(b"mlp_precision", 8) == -3 and L.nerf_set_option(b"ring_split", 3) == -3
     assert L.nerf_get_option(b"mlp_precision") == 16 and L.nerf_get_option(b"ring_split") == 1
