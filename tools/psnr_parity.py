@@ -242,7 +242,36 @@ def main():
     ap.add_argument("--extra", default="", help="comma list of extra witnesses: hip2, emu, hip32 (see run())")
     ap.add_argument("--cross", action="store_true", help="same-weights cross checks at every checkpoint (see run())")
     ap.add_argument("--oracle-until", type=int, default=None, help="stop stepping the oracle trainer after this iteration")
+    ap.add_argument("--seeds", type=int, default=0, help="run this many different (alive) seeds one after the other and print "
+                    "mean / std of the held-out PSNR of both trainers over the seeds at every checkpoint: training is chaotic, "
+                    "so a systematic difference between the implementations shows in the ensemble, not in one trajectory")
     a = ap.parse_args()
+    if a.seeds > 0:
+        arch = O.NerfArch()
+        seeds, nxt = [], 0
+        while len(seeds) < a.seeds:
+            sd = alive_seed(arch, not a.no_quirks, nxt)
+            seeds.append(sd)
+            nxt = sd + 2                                   # the fine network uses seed + 1
+        table = {}
+        for sd in seeds:
+            recs = run(hw=a.hw, n_rand=a.n_rand, iters=a.iters, every=a.every, views=a.views, test_views=a.test_views,
+                       n_importance=a.n_importance, seed=sd, quirks=not a.no_quirks, lrate_decay=a.lrate_decay,
+                       oracle_device=a.oracle_device, eval_chunk=a.eval_chunk, threads=a.threads,
+                       extra=tuple(x for x in a.extra.split(",") if x), cross=a.cross,
+                       emit=lambda rec: print(json.dumps(rec), flush=True))
+            for r in recs:
+                table.setdefault(r["iter"], []).append((r["psnr_hip"], r["psnr_oracle"]))
+        for it, v in sorted(table.items()):
+            h, o = np.array([x[0] for x in v]), np.array([x[1] for x in v])
+            ok = np.isfinite(h) & np.isfinite(o)           # a seed whose training blows up (NaN under the reference's un-activated
+            bad = [sd for sd, k in zip(seeds, ok) if not k]   # sigma: exp(+large) * 0) does so in both trainers; it is listed, not averaged
+            h, o, v = h[ok], o[ok], [x for x, k in zip(v, ok) if k]
+            print(json.dumps({"ensemble_iter": it, "seeds": seeds, "seeds_nan_in_both": bad, "psnr_hip_mean": float(h.mean()), "psnr_hip_std": float(h.std()),
+                              "psnr_oracle_mean": float(o.mean()), "psnr_oracle_std": float(o.std()),
+                              "mean_delta_db": float((h - o).mean()), "std_of_delta_db": float((h - o).std()),
+                              "standard_error_of_mean_delta_db": float((h - o).std() / np.sqrt(len(v)))}), flush=True)
+        return
     run(hw=a.hw, n_rand=a.n_rand, iters=a.iters, every=a.every, views=a.views, test_views=a.test_views,
         n_importance=a.n_importance, seed=a.seed, quirks=not a.no_quirks, lrate_decay=a.lrate_decay,
         oracle_device=a.oracle_device, eval_chunk=a.eval_chunk, threads=a.threads,
