@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- train+render rays/s of the MI355X-native NeRF hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or alone -- it then starts
+                                                             its N ranks itself before touching the GPU)
 
 One "step" = one training iteration of the reference loop (entrypoints/__test_nerf.py:200-305:
 N_rand rays, coarse 64 + fine 64+128 samples, forward + backward + Adam for both networks) PLUS
