@@ -330,7 +330,7 @@ def _host_cores():
 
 def cpu_baseline(args):
     """The CPU oracle (op-for-op torch-CPU fp32 restatement of the reference path, `kind: port`) at the size SURVEY
-    8(d) specifies: training at B = 1024 rays (lego.txt N_rand), 1 warm-up + up to 20 timed steps, and a render slice
+    8(d) specifies: training at B = 1024 rays (lego.txt N_rand), 3 warm-up + up to 20 timed steps, and a render slice
     of 65 536 rays in 4096-ray chunks (coarse 64 + fine 64+128 like the GPU step; coarse-only when --n-importance 0).
     Each leg is time-boxed (about 60 s) so that a slow host still finishes: the steps / rays actually timed are in
     `sample`.  `value` combines the two legs in the GPU step's train : render ray mix."""
@@ -346,7 +346,8 @@ def cpu_baseline(args):
     d = -o / 4.0 + 0.2 * torch.randn(n_render, 3, generator=g)
     y = torch.rand(b_train, 3, generator=g)
     un = max(NI, 1)
-    tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))          # warm-up
+    for _ in range(3):                                                                   # 3 warm-up steps
+        tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))
     t0 = time.perf_counter()
     steps = 0
     while steps < 20 and (steps < 3 or time.perf_counter() - t0 < 60.0):
