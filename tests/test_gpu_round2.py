@@ -379,9 +379,10 @@ def test_checkpoint_npz_roundtrip_continues(tmp_path, kind, shared):
     """save() mid-training -> load() into a FRESH trainer: the restored state is BIT-identical to the saved one --
     parameters, Adam (m, v) per state key (shared, or coarse / fine, or mlp / tables), step counts (the NGP loop uses
     bias correction), iteration (LR schedule) and both RNG streams (the next batch is the same rays, bit for bit) --
-    and training continues on the same trajectory.  The continuation itself is compared at fp32 summation-noise level
-    (losses 1e-5 relative, parameters 1e-6 absolute), not bitwise: the weight-gradient kernel adds split-K partial
-    tiles with float atomics, whose order differs from launch to launch, in one process as much as across a restart.
+    and training continues on the same trajectory: BIT-identical parameters after two more iterations for the 8 x 256
+    trainer (its kernels are deterministic since the split-K partial tiles are reduced in a fixed order; the reported
+    loss scalar is still an atomic sum, compared at 1e-5), fp32 summation-noise level for the hash-grid trainer (its
+    table gradients are scattered with float atomics, whose order differs from launch to launch).
     The path is given without ".npz" on purpose (np.savez appends it; load() must find it)."""
     a = _mini_trainer(kind, shared)
     for _ in range(3):
@@ -409,11 +410,14 @@ def test_checkpoint_npz_roundtrip_continues(tmp_path, kind, shared):
         for k in x:
             assert abs(float(x[k]) - float(y[k])) <= 1e-5 * abs(float(x[k])), (k, float(x[k]), float(y[k]))
     for k, ma in a._checkpoint_buffers().items():
-        diff = (ma.params - b._checkpoint_buffers()[k].params).abs()
-        # Adam without bias correction steps by lr * m / (sqrt(v) + eps): for a weight whose gradient is zero up to
-        # summation noise that ratio is noise of order one, so single weights may differ by a fraction of lr (5e-4);
-        # the bulk agrees to float32 resolution
-        assert float(diff.max()) < 1e-3 and float(diff.mean()) < 1e-6, (k, float(diff.max()), float(diff.mean()))
+        if kind == "nerf":
+            # the 8 x 256 trainer is bit-reproducible since the split-K partial tiles are reduced in a fixed order
+            assert torch.equal(ma.params, b._checkpoint_buffers()[k].params), k
+        else:
+            diff = (ma.params - b._checkpoint_buffers()[k].params).abs()
+            # hash-table gradients are scattered with float atomics (order-dependent rounding), and Adam steps by
+            # lr * m / (sqrt(v) + eps): for an entry whose gradient is zero up to that noise the ratio is noise of order one
+            assert float(diff.max()) < 1e-3 and float(diff.mean()) < 1e-6, (k, float(diff.max()), float(diff.mean()))
     # state_dict round trip in memory too
     c = _mini_trainer(kind, shared)
     c.load_state_dict(a.state_dict())
@@ -435,8 +439,8 @@ def test_entrypoint_checkpoint_flags(tmp_path):
     assert [os.path.basename(p) for p in r2["checkpoints"]] == ["000008.npz"]
     for x, y in zip(r2["losses"][-1][1:], full["losses"][-1][1:]):                 # same trajectory as the uninterrupted run
         assert abs(x - y) <= 1e-4 * abs(y), (r2["losses"][-1], full["losses"][-1])   # (float atomics: not bitwise)
-    dpar = (r2["trainer"].fine.params - full["trainer"].fine.params).abs()
-    assert float(dpar.max()) < 2e-3 and float(dpar.mean()) < 2e-6, (float(dpar.max()), float(dpar.mean()))
+    assert torch.equal(r2["trainer"].fine.params, full["trainer"].fine.params)      # resumed == uninterrupted, bit for bit
+    assert torch.equal(r2["trainer"].coarse.params, full["trainer"].coarse.params)
     r3 = test_nerf.main(None, max_iter=5, argv=base + ["--no_reload"], **kw)
     assert r3["resumed_from"] is None and r3["losses"][0][0] == 1
     r4 = test_nerf.main(None, max_iter=9, argv=base + ["--no_reload", "--ft_path", r1["checkpoints"][0]], **kw)
