@@ -1,0 +1,213 @@
+"""CPU suite: pin the oracle's READING of the MLX-dependent rows (a2, a4-a7, a9-a14, a18-a20, a23-a25) against
+fixtures produced by the reference's OWN source executed over a numpy-backed `mx` shim in the build container
+(tests/golden/make_golden_mx.py -> tests/golden/ref_mx_*.npz|json).
+
+What these pin: op order, shapes, concatenation orders and quirks (k^2 bands, un-ReLU'd exclusive cumsum, no
+sigmoid, [B,n,1] weights, kwargs aliasing).  What they do not pin: MLX's own float behaviour (the shim is float32
+numpy) -- tolerances are a few float32 ulps of the value scale; GEMM chains get 2e-5 of the output scale."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+
+def _npz(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    with open(os.path.join(golden_dir, "ref_mx_meta.json")) as fp:
+        return json.load(fp)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(got, want, atol, rtol=0.0, nan_ok=True):
+    np.testing.assert_allclose(np.asarray(got), np.asarray(want), atol=atol, rtol=rtol, equal_nan=nan_ok)
+
+
+def params_from_seed(layers, seed, checksum, alpha=(1.0, 0.0)):
+    """Rebuild a network from (layer list, seed) exactly as make_golden_mx.draw_weights / inject did."""
+    arch_layers = [(n, int(o), int(i)) for n, o, i in layers]
+    rng = np.random.default_rng(seed)
+    p = {}
+    for name, o, i in arch_layers:
+        k = 1.0 / np.sqrt(i)
+        w = rng.uniform(-k, k, size=(o, i)).astype(np.float32)
+        b = rng.uniform(-k, k, size=(o,)).astype(np.float32)
+        p[name] = (w, b)
+    got = float(sum(np.abs(p[n][0].astype(np.float64)).sum() + np.abs(p[n][1].astype(np.float64)).sum() for n, _, _ in arch_layers))
+    assert abs(got - checksum) <= 1e-9 * checksum, "weight reconstruction differs from the generator's"
+    if "alpha" in p:
+        s, b0 = np.float32(alpha[0]), np.float32(alpha[1])
+        p["alpha"] = (p["alpha"][0] * s, p["alpha"][1] * s + b0)
+    return {k: (T(w), T(b)) for k, (w, b) in p.items()}
+
+
+def arch_of(ctor):
+    return O.NerfArch(channel_input=ctor["channel_input"], channel_input_views=ctor["channel_input_views"],
+                      channel_output=ctor["channel_output"], n_layers=ctor["n_layers"], width=ctor["width_layers"],
+                      skips=tuple(ctor["list_skip_connection_layers"]), use_viewdirs=ctor["is_use_view_directions"])
+
+
+# ------------------------------------------------------------------------------------------------ a13
+def test_raw2outputs_matches_reference_source(golden_dir, meta):
+    g = _npz(golden_dir, "ref_mx_raw2outputs.npz")
+    for c in meta["raw2outputs"]["cases"]:
+        t = c["tag"]
+        rgb, disp, acc, w, depth = O.raw2outputs(T(g[f"{t}_raw"]), T(g[f"{t}_z"]), T(g[f"{t}_d"]), 0.0, c["white_bkgd"])
+        assert tuple(w.shape) == g[f"{t}_weights"].shape and w.shape[-1] == 1
+        sc = max(1.0, float(np.nanmax(np.abs(g[f"{t}_weights"]))))
+        close(w, g[f"{t}_weights"], atol=2e-6 * sc, rtol=2e-5)           # T = exp(+large) for negative sigma: relative
+        close(acc, g[f"{t}_acc"], atol=1e-5 * sc, rtol=2e-5)
+        close(rgb, g[f"{t}_rgb"], atol=1e-5 * sc, rtol=5e-5)
+        close(depth, g[f"{t}_depth"], atol=1e-5 * sc, rtol=5e-5)
+        # disparity = 1/max(1e-10, depth/acc): NaN where acc == 0 (Q11), same places in both
+        assert np.array_equal(np.isnan(disp.numpy()), np.isnan(g[f"{t}_disp"]))
+        ok = np.isfinite(g[f"{t}_disp"]) & (np.abs(g[f"{t}_acc"]) > 1e-3)
+        close(disp.numpy()[ok], g[f"{t}_disp"][ok], atol=0, rtol=2e-4)
+    rgb, disp, acc, w, depth = O.raw2outputs(T(g["noise_raw"]), T(g["noise_z"]), T(g["noise_d"]), meta["raw2outputs"]["noise_std"], True,
+                                             noise=T(g["noise_noise"]))
+    close(w, g["noise_weights"], atol=2e-6, rtol=2e-5)
+    close(rgb, g["noise_rgb"], atol=1e-5, rtol=5e-5)
+
+
+# ------------------------------------------------------------------------------------------------ a9 a10 a23 a24
+def test_encodings_match_reference_source(golden_dir, meta):
+    g = _npz(golden_dir, "ref_mx_encodings.npz")
+    e = meta["embedder"]
+    assert (e["out_dim_10"], e["out_dim_4"], e["out_dim_identity"]) == (63, 27, 3)
+    x3, dirs = T(g["x3"]), T(g["dirs"])
+    # sin/cos of arguments up to 81 * 4: numpy vs torch float32 sin agree to ~1 ulp of the result
+    close(O.embedder(x3, 10), g["emb10"], atol=3e-6)
+    close(O.embedder(dirs, 4), g["emb4"], atol=1e-6)
+    # k^2 bands (Q4): band 0 is frequency 0 -> sin = 0, cos = 1 for every input
+    assert np.all(g["emb10"][:, 3:6] == 0) and np.all(g["emb10"][:, 6:9] == 1)
+    assert np.array_equal(g["ident"], g["x3"])
+    close(O.embed(T(g["embed_pos"]), T(g["embed_dir"])), g["embed_out"], atol=3e-6)
+    close(O.embed(T(g["embed_pos"]), None), g["embed_out_nodir"], atol=3e-6)
+    s = meta["sinusoidal"]
+    assert s["img"]["out_dim"] == 40 and s["inc"]["out_dim"] == 27 and s["frac"]["out_dim"] == 30
+    # integer pixel coordinates up to 399 * 256: |arg| ~ 1e5, one float32 ulp of the argument is 8e-3 rad,
+    # so the product rounding must be the reference's; both sides form x*f in float32 from the same f
+    close(O.sinusoidal_encoding(T(g["sin_xi"]), 10, 0.0, 8.0, False), g["sin_img"], atol=8e-3)
+    close(O.sinusoidal_encoding(T(g["sin_xi"]), 10, 0.0, 8.0, False)[:, :5], g["sin_img"][:, :5], atol=1e-4)
+    close(O.sinusoidal_encoding(x3, 4, None, None, True), g["sin_inc"], atol=2e-6)
+    close(O.sinusoidal_encoding(x3, 5, -1.0, 2.5, False), g["sin_frac"], atol=5e-6)
+    for deg in range(5):
+        close(O.sh_encoding(dirs, deg), g[f"sh{deg}"], atol=1e-6)
+    assert np.array_equal(g["identity_enc"], g["x3"])
+
+
+# ------------------------------------------------------------------------------------------------ a11 a12
+@pytest.mark.parametrize("tag", ["view", "image", "ngp"])
+def test_mlp_forward_matches_reference_source(golden_dir, meta, tag):
+    g = _npz(golden_dir, "ref_mx_mlp.npz")
+    net = meta["mlp"]["nets"][tag]
+    arch = arch_of(net["ctor"])
+    assert [(n, o, i) for n, o, i in arch.layer_shapes()] == [tuple(l) for l in net["layers"]]   # ctor shapes == reference's
+    p = params_from_seed(net["layers"], net["seed"], net["checksum"])
+    out = O.nerf_forward(arch, p, T(g[f"{tag}_x"]))
+    sc = float(np.abs(g[f"{tag}_out"]).max())
+    close(out, g[f"{tag}_out"], atol=2e-5 * sc)
+
+
+def test_run_model_matches_reference_source(golden_dir, meta):
+    g = _npz(golden_dir, "ref_mx_mlp.npz")
+    net = meta["mlp"]["nets"]["view"]
+    arch = arch_of(net["ctor"])
+    p = params_from_seed(net["layers"], net["seed"], net["checksum"])
+    out = O.run_model(arch, p, T(g["run_pos"]), T(g["run_dir"]), netchunk=meta["mlp"]["run_model_netchunk"])
+    assert tuple(out.shape) == g["run_out"].shape == (7, 9, 4)
+    close(out, g["run_out"], atol=2e-5 * float(np.abs(g["run_out"]).max()))
+    assert meta["mlp"]["run_model_rank2_raises"] == "AssertionError"
+    with pytest.raises(AssertionError):
+        O.run_model(arch, p, T(g["run_pos"]).reshape(-1, 3), T(g["run_dir"]))
+
+
+# ------------------------------------------------------------------------------------------------ a2 a4 a5 a6 a7 a20 a25
+def test_sampling_rays_metric_pose_match_reference_source(golden_dir, meta):
+    g = _npz(golden_dir, "ref_mx_misc.npz")
+    near, far = T(g["near"]), T(g["far"])
+    assert torch.equal(O.sample_z_uniform(near, far, 64), T(g["z_uniform_64"]))
+    assert torch.equal(O.sample_z_uniform(near, far, 5), T(g["z_uniform_5"]))
+    zl = O.sample_z_lindisp(near, far, 64)
+    assert np.array_equal(zl.numpy(), g["z_lindisp_64"]) and float(zl[:, 0].abs().max()) == 0 and float(zl[:, -1].abs().max()) == 0   # Q12
+    assert np.array_equal(g["noise0"], g["z_uniform_64"])                      # strength <= 0 returns z itself
+    assert torch.equal(O.add_noise_z(T(g["z_uniform_64"]), 0.0), T(g["z_uniform_64"]))
+    assert meta["sampling"]["add_noise_z_jitter_raises"] is not None           # Q6: the committed jitter branch cannot run
+    n = meta["sampling"]["ndc"]
+    no, nd = O.ndc_rays(n["H"], n["W"], n["focal"], n["near"], T(g["ndc_o_in"]), T(g["ndc_d_in"]))
+    close(no, g["ndc_o"], atol=0, rtol=2e-6); close(nd, g["ndc_d"], atol=1e-6, rtol=2e-6)
+    o, d, nr, fr, vd = O.decompose_ray_batch(T(g["rays_linear"]))
+    for got, key in ((o, "dec_o"), (d, "dec_d"), (nr, "dec_near"), (fr, "dec_far"), (vd, "dec_viewdirs")):
+        assert np.array_equal(got.numpy(), g[key])
+    close(O.mse(T(g["metric_a"]), T(g["metric_b"])), g["mse"], atol=0, rtol=1e-6)
+    close(O.psnr(T(g["metric_a"]), T(g["metric_b"])), g["psnr"], atol=0, rtol=1e-6)
+    for args, want in zip(g["pose_args"], g["pose_out"]):
+        close(O.pose_spherical(*[float(a) for a in args]), want, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ create_NeRF, a14 a18 a19
+def test_create_nerf_kwargs_match_reference_source(meta):
+    from nerf_meets_mlx_amd import config_parser as C
+    c = meta["create_NeRF"]
+    # Q5: test kwargs alias the train kwargs -> perturb False, raw_noise_std 0, render_rays_eval, is_test False
+    assert c["alias"] and c["render_rays_func"] == "render_rays_eval"
+    assert c["values"]["perturb"] is False and c["values"]["raw_noise_std"] == 0 and c["values"]["is_test"] is False
+    assert c["optimizer"] == {"betas": [0.9, 0.999], "learning_rate": C.config_parser().parse_args(args=[]).lrate}
+    assert set(c["keys"]) == {"use_viewdirs", "white_bkgd", "network_query_fn", "is_test", "render_rays_func", "network_coarse",
+                              "n_depth_samples", "network_fine", "perturb", "raw_noise_std", "N_importance", "ndc", "lindisp"}
+
+
+def _render_nets(meta):
+    r = meta["render"]
+    arch = O.NerfArch()
+    assert [list(t) for t in arch.layer_shapes()] == r["layers"]
+    pc = params_from_seed(r["layers"], r["seeds"]["coarse"], r["checksum"]["coarse"], r["alpha_scale_bias"]["coarse"])
+    pf = params_from_seed(r["layers"], r["seeds"]["fine"], r["checksum"]["fine"], r["alpha_scale_bias"]["fine"])
+    return arch, pc, pf, r
+
+
+def test_render_rays_matches_reference_source(golden_dir, meta):
+    g = _npz(golden_dir, "ref_mx_render.npz")
+    arch, pc, pf, r = _render_nets(meta)
+    ret = O.render_rays(arch, pc, T(g["rr_rays"]), r["n_depth_samples"], white_bkgd=True, retraw=True)
+    assert torch.equal(ret["z_vals"], T(g["rr_z_vals"]))
+    sc = float(np.abs(g["rr_raw"]).max())
+    close(ret["raw"], g["rr_raw"], atol=3e-5 * sc)
+    assert tuple(ret["weights"].shape) == g["rr_weights"].shape == (40, 64, 1)
+    assert float(np.abs(g["rr_weights"]).max()) > 0.05                          # the fixture's CDF is not flat
+    close(ret["weights"], g["rr_weights"], atol=5e-6)
+    close(ret["rgb_map"], g["rr_rgb_map"], atol=5e-6); close(ret["acc_map"], g["rr_acc_map"], atol=5e-6)
+    assert np.array_equal(g["rr_rgb_map"], g["rr_rgb_coarse"]) and np.array_equal(g["rr_acc_map"], g["rr_acc_coarse"])
+
+
+def test_render_rays_eval_and_render_match_reference_source(golden_dir, meta):
+    g = _npz(golden_dir, "ref_mx_render.npz")
+    arch, pc, pf, r = _render_nets(meta)
+    ret = O.render_rays_eval(arch, pc, pf, T(g["rr_rays"]), r["n_depth_samples"], r["N_importance"], T(g["re_u"]), white_bkgd=True)
+    close(ret["rgb_coarse"], g["re_rgb_coarse"], atol=5e-6)
+    close(ret["weights"], g["re_weights"], atol=5e-6)
+    close(ret["rgb_map"], g["re_rgb_map"], atol=2e-5); close(ret["acc_map"], g["re_acc_map"], atol=2e-5)
+    assert float(np.abs(g["re_rgb_map"] - g["re_rgb_coarse"]).max()) > 1e-3    # the fine pass really is a different net / sample set
+    # full render(): get_rays -> pack -> chunks of 50 (ragged tail) -> reshape to [H,W,...] -> [rgb, disp, acc, extras]
+    H, W = (int(v) for v in g["render_HW"])
+    out = O.render(arch, pc, pf, H, W, g["render_K"], g["render_c2w"], r["near"], r["far"], r["n_depth_samples"], r["N_importance"],
+                   T(g["render_u"]), chunk=int(g["render_chunk"]), white_bkgd=True)
+    rgb, disp, acc, extras = out
+    assert tuple(rgb.shape) == (H, W, 3) and tuple(disp.shape) == (H, W, 1) and tuple(acc.shape) == (H, W, 1)
+    close(rgb, g["render_rgb"], atol=2e-5); close(acc, g["render_acc"], atol=2e-5)
+    ok = np.abs(g["render_acc"]) > 1e-2
+    close(disp.numpy()[ok], g["render_disp"][ok], atol=0, rtol=5e-3)
+    assert set(meta["render"]["extras_keys"]) <= set(extras.keys()) | {"rgb_coarse", "disp_coarse", "acc_coarse", "z_vals", "weights"}
+    assert tuple(extras["weights"].shape) == g["render_extra_weights"].shape == (H, W, 64, 1)
+    assert torch.equal(extras["z_vals"], T(g["render_extra_z_vals"]))
+    close(extras["rgb_coarse"], g["render_extra_rgb_coarse"], atol=5e-6)
