@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 FLOP_PER_SAMPLE_FWD = 2 * 593408          # SURVEY 8d / BASELINE.md section 2
 BF16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA
+FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
 TRAIN_BYTES_PER_SAMPLE = (321 + 356 + 9) * 1024 / 32      # HBM bytes per sample of a training pass (8 TB/s peak)
 
 
@@ -44,6 +45,10 @@ def main():
     ap.add_argument("--hw", type=int, default=800)
     ap.add_argument("--train-images", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained / fp32 / ngp legs of the default N=1 line")
+    ap.add_argument("--sustain-seconds", type=float, default=10.0, help="length of the sustained bf16 leg")
+    ap.add_argument("--fp32-steps", type=int, default=8, help="timed steps of the fp32 (reference arithmetic) leg")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="time box of each cpu_baseline leg")
     ap.add_argument("--mlp-variant", type=int, default=0)
     ap.add_argument("--n-importance", type=int, default=128, help="0 = coarse-only (BASELINE configs[1] with --hw 400)")
     ap.add_argument("--config", choices=["nerf", "ngp"], default="nerf",
@@ -71,85 +76,91 @@ def main():
     imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, args.train_images, seed=0, device=dev)
     if args.config == "ngp":
         return bench_ngp(args, imgs, poses, rposes, K, rank, world, dev)
-    # seed 4: both networks start with sigma > 0 (a net whose raw sigma starts negative everywhere has an exactly
-    # zero gradient under the reference's formulas and never trains -- DESIGN.md section 8)
-    tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=args.n_importance, seed=4, device=dev,
-                 chunk=args.render_rays)
     # render chunk of this rank: a contiguous slice of a render pose's pixel list, resident on the device
     lo, _ = parallel.shard_range(H * W, rank, world)
     lo = min(lo, H * W - args.render_rays)
     ridx = torch.arange(lo, lo + args.render_rays, device=dev, dtype=torch.int64)
     rrays = ray.gen_rays(H, W, K, rposes[40][:3, :4], 2.0, 6.0, ridx)
-    ev = {"t": []}
-
-    def timed_fine_query(r, zf):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        raw = (tr.fine or tr.coarse).query(r, zf, ref_quirks=True)
-        e1.record()
-        ev["t"].append((e0, e1))
-        return raw
 
     from nerf_meets_mlx_amd import sampling
     from nerf_meets_mlx_amd.rendering import render
 
     NI = args.n_importance
     n_fine = 64 + NI
-
-    def render_chunk():
-        z = sampling.sample_coarse(rrays, 64)
-        if NI == 0:
-            raw = timed_fine_query(rrays, z) if tr.fine is None else tr.coarse.query(rrays, z)
-            return render.composite(raw, z, rrays, 0.0, True, need_weights=False)[0]
-        raw = tr.coarse.query(rrays, z)
-        _, _, _, w, _ = render.composite(raw, z, rrays, 0.0, True)
-        u = torch.rand(rrays.shape[0], NI, device=dev, generator=tr.gen)
-        _, zf = sampling.importance_sample(z, w, NI, u=u)
-        raw = timed_fine_query(rrays, zf)
-        return render.composite(raw, zf, rrays, 0.0, True, need_weights=False)[0]
-
-    phase = {"train": [], "render": []}
-
-    def step():
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        e[0].record()
-        out = tr.train_step()
-        e[1].record()
-        rgb = render_chunk()
-        e[2].record()
-        phase["train"].append((e[0], e[1])); phase["render"].append((e[1], e[2]))
-        return out, rgb
+    spr = (64 + n_fine) if NI > 0 else 64
 
     def barrier():
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ev["t"].clear(); phase["train"].clear(); phase["render"].clear()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, rgb = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t[0])
-    assert torch.isfinite(rgb).all() and torch.isfinite(out["loss_coarse"]).all()
+    def measure(precision, steps, warmup):
+        """`steps` timed steps (train N_rand rays + render one chunk) of a fresh Trainer at `precision`, after `warmup`
+        untimed ones, bracketed by barrier + synchronize; the dominant kernel (fused MLP forward of the render fine
+        pass) and both phases are timed with events on the launch stream inside the timed region."""
+        # seed 4: both networks start with sigma > 0 (a net whose raw sigma starts negative everywhere has an exactly
+        # zero gradient under the reference's formulas and never trains -- DESIGN.md section 7)
+        tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=NI, seed=4, device=dev,
+                     chunk=args.render_rays, precision=precision)
+        ev, phase = [], {"train": [], "render": []}
 
-    rays_per_step = (args.n_rand + args.render_rays) * world
-    value = rays_per_step * args.steps / dt
+        def timed_fine_query(r, zf):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            raw = (tr.fine or tr.coarse).query(r, zf, ref_quirks=True)
+            e1.record()
+            ev.append((e0, e1))
+            return raw
+
+        def render_chunk():
+            z = sampling.sample_coarse(rrays, 64)
+            if NI == 0:
+                raw = timed_fine_query(rrays, z) if tr.fine is None else tr.coarse.query(rrays, z)
+                return render.composite(raw, z, rrays, 0.0, True, need_weights=False)[0]
+            raw = tr.coarse.query(rrays, z)
+            _, _, _, w, _ = render.composite(raw, z, rrays, 0.0, True)
+            u = torch.rand(rrays.shape[0], NI, device=dev, generator=tr.gen)
+            _, zf = sampling.importance_sample(z, w, NI, u=u)
+            raw = timed_fine_query(rrays, zf)
+            return render.composite(raw, zf, rrays, 0.0, True, need_weights=False)[0]
+
+        def step():
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            out = tr.train_step()
+            e[1].record()
+            rgb = render_chunk()
+            e[2].record()
+            phase["train"].append((e[0], e[1])); phase["render"].append((e[1], e[2]))
+            return out, rgb
+
+        for _ in range(warmup):
+            step()
+        ev.clear(); phase["train"].clear(); phase["render"].clear()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, rgb = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t[0])
+        assert torch.isfinite(rgb).all() and torch.isfinite(out["loss_coarse"]).all()
+        t_train = float(np.mean([a.elapsed_time(b) for a, b in phase["train"]])) * 1e-3
+        t_render = float(np.mean([a.elapsed_time(b) for a, b in phase["render"]])) * 1e-3
+        return {"dt": dt, "steps": steps, "value": (args.n_rand + args.render_rays) * world * steps / dt,
+                "ms_per_step": dt / steps * 1e3, "k_ms": float(np.mean([a.elapsed_time(b) for a, b in ev])),
+                "t_train": t_train, "t_render": t_render, "loss_coarse": float(out["loss_coarse"]),
+                "loss_fine": float(out.get("loss_fine", torch.zeros(1)))}
+
+    m = measure(16, args.steps, args.warmup)                       # THE timed region of the contract
+    dt, value, k_ms, t_train, t_render = m["dt"], m["value"], m["k_ms"], m["t_train"], m["t_render"]
     # dominant kernel: fused MLP forward over render_rays x 192 samples
-    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["t"]]))
     flop = FLOP_PER_SAMPLE_FWD * args.render_rays * n_fine
     # per-phase throughput (events on the launch stream) and algorithmic MFMA fractions (SURVEY 8d: train = 3x forward
     # FLOPs over 64 + n_fine samples, render = 1x; the repeated coarse forward of __test_nerf.py:270 is not credited)
-    t_train = float(np.mean([a.elapsed_time(b) for a, b in phase["train"]])) * 1e-3
-    t_render = float(np.mean([a.elapsed_time(b) for a, b in phase["render"]])) * 1e-3
-    spr = (64 + n_fine) if NI > 0 else 64
     train_tf = 3 * FLOP_PER_SAMPLE_FWD * spr * args.n_rand / t_train / 1e12
     render_tf = FLOP_PER_SAMPLE_FWD * spr * args.render_rays / t_render / 1e12
     achieved = flop / (k_ms * 1e-3) / 1e12
@@ -187,13 +198,40 @@ def main():
         # the training phase against its other roofline: bf16 activations + dZ written once (321 KiB per 32-sample tile)
         # and read once by the weight-gradient jobs (356 KiB) + sign-bit words (9 KiB) = 21.4 KB per sample
         "train_hbm_frac": TRAIN_BYTES_PER_SAMPLE * spr * args.n_rand / t_train / 8e12,
-        "loss_coarse": float(out["loss_coarse"]), "loss_fine": float(out.get("loss_fine", torch.zeros(1))),
+        "loss_coarse": m["loss_coarse"], "loss_fine": m["loss_fine"],
         "roofline": {"bound": "mfma", "kernel": ("mlp_fwd_ring16_kernel<8,2>" if args.mlp_variant in (0, 4) else f"fused MLP forward, mlp_variant {args.mlp_variant}") + " (render fine pass)", "achieved": achieved,
                      "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "traffic_source": traffic_src,
                      "mfma_busy_cycles_frac": busy, "mfma_busy_source": busy_src, "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
                      "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * n_fine},
     }
+    if world == 1 and not args.no_extra_legs:
+        # ---- sustained: the same bf16 step for >= args.sustain_seconds (the burst above is < 1 s of a power-limited
+        # kernel; this is what the chip holds, and long enough for an SMI sampler to see the GPU busy)
+        n_sus = max(args.steps, int(np.ceil(args.sustain_seconds * 1.05 / (dt / args.steps))))
+        ms = measure(16, n_sus, 2)
+        line["sustained"] = {"seconds": ms["dt"], "steps": n_sus, "value": ms["value"], "unit": "rays/s",
+                             "ms_per_step": ms["ms_per_step"], "ms_per_launch": ms["k_ms"],
+                             "roofline_frac": flop / (ms["k_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                             "train_rays_per_s": args.n_rand / ms["t_train"], "render_rays_per_s": args.render_rays / ms["t_render"],
+                             "ratio_to_burst": ms["value"] / value, "dtype": "bf16"}
+        # ---- fp32: the same step at the REFERENCE's arithmetic (models/NeRF.py:201-243 runs in MLX float32):
+        # Trainer(precision=32) -> float32 operands on v_mfma_f32_32x32x2_f32, against the fp32 matrix peak
+        m32 = measure(32, args.fp32_steps, 2)
+        a32 = flop / (m32["k_ms"] * 1e-3) / 1e12
+        line["fp32"] = {"value": m32["value"], "unit": "rays/s", "steps": args.fp32_steps, "ms_per_step": m32["ms_per_step"],
+                        "train_rays_per_s": args.n_rand / m32["t_train"], "render_rays_per_s": args.render_rays / m32["t_render"],
+                        "dtype": "f32", "loss_coarse": m32["loss_coarse"], "loss_fine": m32["loss_fine"],
+                        "train_mfma_frac": 3 * FLOP_PER_SAMPLE_FWD * spr * args.n_rand / m32["t_train"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        "render_mfma_frac": FLOP_PER_SAMPLE_FWD * spr * args.render_rays / m32["t_render"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        "roofline": {"bound": "mfma", "kernel": "mlp32_fwd_kernel (render fine pass)", "achieved": a32,
+                                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a32 / FP32_MFMA_PEAK_TFLOPS,
+                                     "ms_per_launch": m32["k_ms"], "samples_per_launch": args.render_rays * n_fine}}
+        # ---- ngp: BASELINE configs[4] (hash grid + 2x64 MLP), its own step and roofline (the table-gradient scatter)
+        ngp_line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev)
+        line["ngp"] = {k: ngp_line[k] for k in ("value", "unit", "ms_per_step", "steps", "train_rays_per_s_per_gpu",
+                                                "render_rays_per_s_per_gpu", "roofline", "dtype", "loss_coarse")}
+        line["ngp"]["workload"] = ngp_line["config"]["workload"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
@@ -251,6 +289,16 @@ def _latest_profile(pattern):
 
 
 def bench_ngp(args, imgs, poses, rposes, K, rank, world, dev):
+    line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_ngp(args)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev):
     """BASELINE configs[4]: hash grid (16 levels x 2^19 x 2) + SH + NeRF 2x64, 64 samples per ray, coarse-only loop.
     Same step structure as the headline bench (train N_rand rays + render one chunk); the dominant kernel is the
     hash-grid gradient scatter (float atomics), reported against the HBM roofline with its algorithmic bytes."""
@@ -310,12 +358,7 @@ def bench_ngp(args, imgs, poses, rposes, K, rank, world, dev):
                      "ms_per_launch": k_ms, "samples_per_launch": M,
                      "note": "atomic-rate bound: 256 float atomics per sample at ~20 G/s (device-scope atomics execute memory-side)"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_ngp(args)
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    return line
 
 
 def _host_cores():
@@ -332,7 +375,7 @@ def cpu_baseline(args):
     """The CPU oracle (op-for-op torch-CPU fp32 restatement of the reference path, `kind: port`) at the size SURVEY
     8(d) specifies: training at B = 1024 rays (lego.txt N_rand), 3 warm-up + up to 20 timed steps, and a render slice
     of 65 536 rays in 4096-ray chunks (coarse 64 + fine 64+128 like the GPU step; coarse-only when --n-importance 0).
-    Each leg is time-boxed (about 60 s) so that a slow host still finishes: the steps / rays actually timed are in
+    Each leg is time-boxed (--cpu-seconds, default 30 s) so that a slow host still finishes: the steps / rays actually timed are in
     `sample`.  `value` combines the two legs in the GPU step's train : render ray mix."""
     from oracle import nerf_oracle as O
     cores = _host_cores()
@@ -350,7 +393,7 @@ def cpu_baseline(args):
         tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))
     t0 = time.perf_counter()
     steps = 0
-    while steps < 20 and (steps < 3 or time.perf_counter() - t0 < 60.0):
+    while steps < 20 and (steps < 3 or time.perf_counter() - t0 < args.cpu_seconds):
         tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))
         steps += 1
     t_train = time.perf_counter() - t0
@@ -359,7 +402,7 @@ def cpu_baseline(args):
     t1 = time.perf_counter()
     done = 0
     with torch.no_grad():
-        while done < n_render and (done < 2 * chunk or time.perf_counter() - t1 < 60.0):
+        while done < n_render and (done < 2 * chunk or time.perf_counter() - t1 < args.cpu_seconds):
             rays = O.pack_rays(o[done:done + chunk], d[done:done + chunk], 2.0, 6.0)
             if NI > 0:
                 O.render_rays_eval(arch, pc, pf, rays, 64, NI, torch.rand(rays.shape[0], NI, generator=g), True)
@@ -394,14 +437,14 @@ def cpu_baseline_ngp(args):
     ng.step(o[:b_train], d[:b_train], y)
     t0 = time.perf_counter()
     steps = 0
-    while steps < 20 and (steps < 3 or time.perf_counter() - t0 < 45.0):
+    while steps < 20 and (steps < 3 or time.perf_counter() - t0 < args.cpu_seconds):
         ng.step(o[:b_train], d[:b_train], y)
         steps += 1
     t_train = time.perf_counter() - t0
     t1 = time.perf_counter()
     done = 0
     with torch.no_grad():
-        while done < n_render and (done < 2 * chunk or time.perf_counter() - t1 < 45.0):
+        while done < n_render and (done < 2 * chunk or time.perf_counter() - t1 < args.cpu_seconds):
             ng.render(O.pack_rays(o[done:done + chunk], d[done:done + chunk], 2.0, 6.0))
             done += chunk
     t_render = time.perf_counter() - t1

@@ -9,7 +9,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer (HBM) owned by the caller unless marked "host";
- *     the library allocates nothing and keeps no state besides the last error string.
+ *     the library allocates nothing.  What a call computes depends only on its arguments: the arithmetic of a
+ *     network (bf16 or fp32 MFMA operands) is a field of its `nerf_mlp_arch`, so models of different precision
+ *     can be used side by side, on any streams.  Process-wide state is limited to the last error string and the
+ *     A/B measurement knobs of nerf_set_option (kernel-variant selection; they never change results' layout,
+ *     buffer sizes or which weight image a launch reads).
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden
  *     synchronisation, safe to capture into a hipGraph.
  *   - tensors are dense row-major float32 unless stated; index tensors are int64.
@@ -29,7 +33,10 @@ extern "C" {
 /* 2 (round 2): nerf_mlp_packed_bytes / nerf_mlp_dz_bytes return larger sizes (fp32 weight streams behind the bf16 image;
  * split-K partial tiles behind the dZ blocks) and nerf_mlp_acts_bytes / _dz_bytes depend on "mlp_precision": callers that
  * always size their buffers with these functions are unaffected; new entry points were only added.                  */
-#define NERF_ABI_VERSION 2
+/* 3 (round 3): `precision` became a field of nerf_mlp_arch (was the process-global option "mlp_precision"):
+ * nerf_mlp_packed_bytes / _acts_bytes / _dz_bytes / _pack and every forward / backward read it from the arch they are
+ * given.  The struct grew by one int at the end; a v2 caller must be recompiled.                                  */
+#define NERF_ABI_VERSION 3
 
 #define NERF_OK 0
 #define NERF_E_NULL (-1)        /* required pointer is NULL                        */
@@ -203,6 +210,12 @@ typedef struct nerf_mlp_arch {
   int skip_layer;   /* 4   */
   int use_viewdirs; /* 1   */
   int out_ch;       /* outputs of `output_linear` when use_viewdirs == 0 (models/NeRF.py:196-197); ignored otherwise */
+  int precision;    /* 0 or 16: bf16 MFMA operands, fp32 accumulate -- the benchmarked mode (BASELINE configs[1-3]);
+                     * 32: the reference's own arithmetic (models/NeRF.py:201-243 runs in MLX float32): float32 operands
+                     * on v_mfma_f32_32x32x2_f32, sinf / cosf encodings; 8 x 256 view model only.  Read by
+                     * nerf_mlp_packed_bytes / nerf_mlp_pack (an fp32 model's image carries the fp32 weight streams behind
+                     * the bf16 one), nerf_mlp_acts_bytes / nerf_mlp_dz_bytes (fp32 stores are larger) and every launch:
+                     * use ONE arch value per model for all of them.                                                  */
 } nerf_mlp_arch;
 
 int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch);
@@ -286,7 +299,8 @@ int nerf_comm_init(void** comm_out, int nranks, int rank, const char* id_host);
 int nerf_allreduce_grads(void* comm, float* grads, int64_t count, void* stream);
 int nerf_comm_destroy(void* comm);
 
-/* runtime selection of kernel variants (for A/B measurement):
+/* runtime selection of kernel variants (for A/B measurement only: none of these changes a result's meaning, a buffer
+ * size or a layout; precision is NOT here, it is nerf_mlp_arch.precision):
  *   "mlp_variant"     0 auto | 1,2 weights via L1 (32 / 64 samples per wave) | 3 LDS ring, 32x32x16 MFMA |
  *                     4 LDS ring, 16x16x32 MFMA, 8 waves x 32 samples (render path only; auto picks it there) |
  *                     5 same with 4 waves x 64 samples.  Training kernels use 3 for every value >= 3.
@@ -295,13 +309,7 @@ int nerf_comm_destroy(void* comm);
  *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)
  *   "ring_split"      1 (default): one 8-wave workgroup per CU behind a 128 KiB weight ring; 2: two independent 4-wave
  *                     workgroups behind 64 KiB rings (training forward / chain only; measured slower)
- *   "mlp_precision"   16 (default): bf16 MFMA operands, fp32 accumulate -- the benchmarked mode (BASELINE configs[1-3]);
- *                     32: the reference's own arithmetic -- float32 operands on v_mfma_f32_32x32x2_f32, sinf / cosf
- *                     encodings (models/NeRF.py:201-243 runs in MLX float32).  8 x 256 view model only.  The mode is
- *                     read by nerf_mlp_pack (builds the fp32 weight streams), nerf_mlp_acts_bytes / nerf_mlp_dz_bytes
- *                     (fp32 stores are larger) and every forward / backward launch: set it BEFORE packing; a launch in
- *                     fp32 mode on an image packed in bf16 mode returns NERF_E_UNSUPPORTED.
- * nerf_get_option returns the current value of "mlp_variant" | "mlp_precision" | "ring_workgroups" | "dw_workgroups",
+ * nerf_get_option returns the current value of "mlp_variant" | "ring_workgroups" | "ring_split" | "dw_workgroups",
  * or -1 for an unknown key.                                                                                        */
 int nerf_set_option(const char* key, int value);
 int nerf_get_option(const char* key);

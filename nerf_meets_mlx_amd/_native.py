@@ -64,7 +64,7 @@ SIGNATURES = {
 class MlpArch(C.Structure):
     """struct nerf_mlp_arch (include/nerf_hip.h)."""
     _fields_ = [("n_layers", _I), ("width", _I), ("in_pos", _I), ("in_dir", _I), ("skip_layer", _I),
-                ("use_viewdirs", _I), ("out_ch", _I)]
+                ("use_viewdirs", _I), ("out_ch", _I), ("precision", _I)]
 
 
 class NerfHipError(RuntimeError):

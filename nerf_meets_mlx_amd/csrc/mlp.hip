@@ -2040,16 +2040,10 @@ static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: L
                                 // 4: ring, 16x16x32 MFMA, 8 waves x 32 samples (inference only), 5: same, 4 waves x 64 samples
 static int g_ring_wgs = 0;       // persistent workgroups of the ring kernels; 0 = one per CU of the current device
 static int g_ring_split = 1;     // training ring kernels: 1 = one 8-wave workgroup per CU (128 KiB ring), 2 = two 4-wave workgroups (64 KiB rings)
-static int g_mlp_precision = 16; // 16: bf16 MFMA operands, fp32 accumulate (benchmarked mode); 32: fp32 reference-precision mode (mlp32.hip)
-// Packed images whose fp32 streams are current (nerf_mlp_pack builds them only in fp32 mode; a launch in fp32 mode on an
-// image packed in bf16 mode must fail loudly instead of running on stale or uninitialised weights).
-static std::mutex g_pack_mu;
-static std::unordered_map<const void*, bool> g_packed_has32;
-static bool packed_has32(const void* packed) {
-  std::lock_guard<std::mutex> lk(g_pack_mu);
-  auto it = g_packed_has32.find(packed);
-  return it != g_packed_has32.end() && it->second;
-}
+// precision of a model = nerf_mlp_arch.precision (ABI 3): 16 (or 0) bf16 MFMA operands with fp32 accumulate, 32 the fp32
+// reference-precision kernels of mlp32.hip.  Nothing process-wide: two models of different precision can be packed,
+// queried and trained side by side on any streams.
+static inline int arch_prec(const nerf_mlp_arch* a) { return a->precision == 32 ? 32 : 16; }
 // CUs of the current device (256 on an MI355X in SPX mode), asked once: the persistent kernels and the dW split are
 // sized to it instead of to a constant
 // Per-device state: the CU count and the "dynamic LDS attribute set" flags belong to the CURRENT device (a process may
@@ -2084,6 +2078,8 @@ static void ensure_lds(K kernel, int bytes) {
 // model (32+16 -> 4, 2 x 64), -1: no HIP kernel
 static int arch_kind(const nerf_mlp_arch* a) {
   if (!a) return -1;
+  if (a->precision != 0 && a->precision != 16 && a->precision != 32) return -1;
+  if (a->precision == 32 && !(a->n_layers == 8 && a->width == 256 && a->use_viewdirs == 1)) return -1;   // fp32 kernels: 8 x 256 view model only
   if (a->n_layers == 2 && a->width == 64 && a->skip_layer < 0 && a->use_viewdirs == 1 && a->in_pos == 32 && a->in_dir == 16) return 2;
   if (a->n_layers != 8 || a->width != 256 || a->skip_layer != 4) return -1;
   if (a->use_viewdirs == 1 && a->in_pos == 63 && a->in_dir == 27) return 0;
@@ -2109,11 +2105,8 @@ extern "C" int nerf_set_option(const char* key, int value) {
     g_ring_split = value;
     return NERF_OK;
   }
-  if (!strcmp(key, "mlp_precision")) {
-    NERF_REQUIRE(value == 16 || value == 32, NERF_E_UNSUPPORTED, "nerf_set_option: mlp_precision must be 16 (bf16 MFMA) or 32 (fp32 MFMA)");
-    g_mlp_precision = value;
-    return NERF_OK;
-  }
+  NERF_REQUIRE(strcmp(key, "mlp_precision") != 0, NERF_E_UNSUPPORTED,
+               "nerf_set_option: \"mlp_precision\" is gone (ABI 3): set nerf_mlp_arch.precision of the model instead");
   if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 0; return NERF_OK; }
@@ -2126,7 +2119,6 @@ extern "C" int nerf_set_option(const char* key, int value) {
 extern "C" int nerf_get_option(const char* key) {
   if (!key) return -1;
   if (!strcmp(key, "mlp_variant")) return g_mlp_variant;
-  if (!strcmp(key, "mlp_precision")) return g_mlp_precision;
   if (!strcmp(key, "ring_workgroups")) return g_ring_wgs;
   if (!strcmp(key, "ring_split")) return g_ring_split;
   if (!strcmp(key, "dw_workgroups")) return g_dw_wgs;
@@ -2139,8 +2131,8 @@ extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) {
 }
 extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
-  // the 8 x 256 view model carries its fp32 streams (reference-precision mode) behind the bf16 image
-  return k == 0 ? L::PACKED_BYTES + f32::PACKED_BYTES : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
+  // an fp32 (precision 32) 8 x 256 view model carries its fp32 streams behind the bf16 image
+  return k == 0 ? L::PACKED_BYTES + (arch_prec(arch) == 32 ? f32::PACKED_BYTES : 0) : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
 }
 static inline const void* packed32_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES; }
 static inline int64_t padded_tiles(int64_t M) { return (((M + 31) / 32) + 7) / 8 * 8; }
@@ -2148,14 +2140,14 @@ extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
   const int64_t b16 = padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16() : small_astride16()) * 16;
-  return (k == 0 && g_mlp_precision == 32) ? f32::acts_bytes(M) : b16;       // the caller asks after setting the mode
+  return (k == 0 && arch_prec(arch) == 32) ? f32::acts_bytes(M) : b16;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
   const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16
                       + DW_PARTIAL_BYTES;                 // + the split-K partial tiles of the weight-gradient kernel
-  return (k == 0 && g_mlp_precision == 32) ? f32::dz_bytes(M) : b16;
+  return (k == 0 && arch_prec(arch) == 32) ? f32::dz_bytes(M) : b16;
 }
 
 #define NERF_ARCH_MSG ": HIP kernels exist for (8x256, skip 4) with in=63+27 view head, or in=40 / no view head / out_ch<=4, and for (2x64, no skip) with in=32+16 view head"
@@ -2189,12 +2181,7 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
                      reinterpret_cast<bf16x8*>(base + L::F16_OFFSET));
   int rc = check_launch("nerf_mlp_pack");
   if (rc) return rc;
-  const bool want32 = g_mlp_precision == 32;
-  if (want32) rc = f32::pack(params, base + L::PACKED_BYTES, as_stream(stream));
-  {
-    std::lock_guard<std::mutex> lk(g_pack_mu);
-    g_packed_has32[packed] = want32 && rc == NERF_OK;
-  }
+  if (arch_prec(arch) == 32) rc = f32::pack(params, base + L::PACKED_BYTES, as_stream(stream));
   return rc;
 }
 
@@ -2308,9 +2295,7 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     return check_launch("mlp forward (image model)");
   }
-  if (g_mlp_precision == 32) {
-    NERF_REQUIRE(packed_has32(packed), NERF_E_UNSUPPORTED,
-                 "nerf_mlp_forward: mlp_precision is 32 but this packed image was built in bf16 mode: call nerf_mlp_pack again");
+  if (arch_prec(arch) == 32) {
     return f32::forward(packed32_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, as_stream(stream));
   }
   return launch_fwd<0>(packed, x, nullptr, nullptr, M, 1, 0, out, acts, stream);
@@ -2329,9 +2314,7 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   NERF_REQUIRE(packed && rays && z && raw, NERF_E_NULL, "nerf_query_fused: NULL pointer");
   NERF_REQUIRE(freq_mode == 0 || freq_mode == 1, NERF_E_UNSUPPORTED, "nerf_query_fused: freq_mode must be 0 or 1");
   NERF_REQUIRE(B * (int64_t)n < (1ll << 31), NERF_E_SHAPE, "nerf_query_fused: B*n must be < 2^31 samples per call");
-  if (g_mlp_precision == 32) {
-    NERF_REQUIRE(packed_has32(packed), NERF_E_UNSUPPORTED,
-                 "nerf_query_fused: mlp_precision is 32 but this packed image was built in bf16 mode: call nerf_mlp_pack again");
+  if (arch_prec(arch) == 32) {
     return f32::forward(packed32_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts, as_stream(stream));
   }
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
@@ -2457,9 +2440,7 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     jobi(LI::Z_OUT, 1, LI::A_H0 + 112, 16, LI::P_WO, 256, 0, arch->out_ch, 256, LI::P_WO + arch->out_ch * 256);   // output
     return launch_dw(di, nji, ntiles, img_params(arch), acts, dz, img_astride16(), img_zstride16(), grads, s);
   }
-  if (g_mlp_precision == 32) {
-    NERF_REQUIRE(packed_has32(packed), NERF_E_UNSUPPORTED,
-                 "nerf_mlp_backward: mlp_precision is 32 but this packed image was built in bf16 mode: call nerf_mlp_pack again");
+  if (arch_prec(arch) == 32) {
     return f32::backward(packed32_of(packed), acts, d_raw, M, dz, grads, s);
   }
   // ---- 1. dZ chain
@@ -2588,7 +2569,7 @@ static bool debug_slot(int kind, int layer, int* slot, int* nfrag) {
 extern "C" int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int layer) {
   int slot = 0, nfrag = 0;
   if (!arch_ok(arch)) return -1;
-  if (g_mlp_precision == 32) return f32::debug_width(kind, layer);
+  if (arch_prec(arch) == 32) return f32::debug_width(kind, layer);
   if (!debug_slot(kind, layer, &slot, &nfrag)) return -1;
   return 16 * nfrag;
 }
@@ -2596,7 +2577,7 @@ extern "C" int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int lay
 extern "C" int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store, int kind, int layer, int64_t M,
                                    float* out, void* stream) {
   NERF_ARCH_CHECK("nerf_mlp_debug_read");
-  if (g_mlp_precision == 32) {
+  if (arch_prec(arch) == 32) {
     NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");
     return M <= 0 ? NERF_OK : f32::debug_read(store, kind, layer, M, out, as_stream(stream));
   }

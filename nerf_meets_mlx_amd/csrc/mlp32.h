@@ -1,5 +1,5 @@
 // fp32 reference-precision instantiation of the fused 8 x 256 chain (mlp32.hip): interface used by the C ABI
-// entry points of mlp.hip when nerf_set_option("mlp_precision", 32) is in effect.
+// entry points of mlp.hip for a model whose nerf_mlp_arch.precision is 32.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

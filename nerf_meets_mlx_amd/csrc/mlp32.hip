@@ -1,4 +1,4 @@
-// fp32 reference-precision mode of the fused 8 x 256 NeRF MLP (nerf_set_option("mlp_precision", 32)).
+// fp32 reference-precision mode of the fused 8 x 256 NeRF MLP (nerf_mlp_arch.precision == 32).
 //
 // The reference computes in float32 (MLX default dtype; models/NeRF.py:201-243, embedding.py:30-71): this file is the
 // same fused chain as mlp.hip with float32 operands on v_mfma_f32_32x32x2_f32 (fp32 matrix peak 157 TFLOP/s, 1/16 of

@@ -30,7 +30,7 @@ class Trainer:
     def __init__(self, images: torch.Tensor, poses: torch.Tensor, K, near: float = 2.0, far: float = 6.0,
                  N_rand: int = 1024, n_depth_samples: int = 64, N_importance: int = 128, lrate: float = 5e-4,
                  lrate_decay: int = 500, white_bkgd: bool = True, ref_quirks: bool = True, seed: int = 0,
-                 device="cuda", chunk: int = 1024 * 32):
+                 device="cuda", chunk: int = 1024 * 32, precision: int = 16):
         self.device = torch.device(device)
         self.images = images.to(self.device, torch.float32).contiguous()      # [N,H,W,3], white-composited
         self.poses = poses.float().cpu()
@@ -42,9 +42,12 @@ class Trainer:
         self.white_bkgd, self.q, self.chunk = white_bkgd, ref_quirks, chunk
         self.rank, self.world = parallel.world()
         self.seed = seed
-        self.rng = np.random.default_rng(parallel.rank_seed(seed, self.rank, 1))          # image choice
+        # Everything random of iteration `it` (image, pixels, importance uniforms) comes from generators seeded with
+        # parallel.counter_seed(seed, rank, stream, it): (seed, rank, it) IS the RNG state, so a checkpoint written by
+        # rank 0 resumes every rank on its own streams.
         mk = lambda s: NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True,
-                            device=self.device, seed=s)
+                            device=self.device, seed=s, precision=precision)
+        self.precision = precision
         self.coarse = mk(seed)                                  # identical initial weights on every rank
         self.fine = mk(seed + 1) if N_importance > 0 else None
         self.coarse.name = "coarse"                             # Adam state keys when the state is not shared
@@ -52,8 +55,18 @@ class Trainer:
             self.fine.name = "fine"
         self.opt = Adam(lrate, betas=(0.9, 0.999), shared_state=ref_quirks)
         self.it = 0
-        self.gen = torch.Generator(device=self.device)
+        self.gen = torch.Generator(device=self.device)                 # evaluation-time uniforms (render_rays without u)
         self.gen.manual_seed(parallel.rank_seed(seed, self.rank, 2))
+        self._train_gen = torch.Generator(device=self.device)          # re-seeded per iteration (train_uniforms)
+
+    def image_choice(self) -> int:
+        """np.random.choice(i_train) of iteration `self.it` (`__test_nerf.py:202`)."""
+        return parallel.counter_seed(self.seed, self.rank, 1, self.it) % int(self.images.shape[0])
+
+    def train_uniforms(self, B: int) -> torch.Tensor:
+        """torch.rand [B, N_importance] of iteration `self.it` (`sampling/__init__.py:140`)."""
+        self._train_gen.manual_seed(parallel.counter_seed(self.seed, self.rank, 2, self.it))
+        return torch.rand(B, self.N, device=self.device, generator=self._train_gen)
 
     # ---------------------------------------------------------------- one network step
     def _step_net(self, model: NeRF, rays, z, target, white: bool):
@@ -67,10 +80,10 @@ class Trainer:
     def sample_batch(self, pixel_idx: Optional[torch.Tensor] = None, img_i: Optional[int] = None):
         """(rays [B,11], target [B,3]); by default one random image, N_rand distinct pixels."""
         if img_i is None:
-            img_i = int(self.rng.integers(0, self.images.shape[0]))            # np.random.choice(i_train)
+            img_i = self.image_choice()
         if pixel_idx is None:                                                  # the usual case: one fused launch
             return ray.sample_batch(self.H, self.W, self.K, self.poses[img_i, :3, :4], self.near, self.far,
-                                    self.images[img_i], self.N_rand, parallel.rank_seed(self.seed, self.rank, 3) + self.it)
+                                    self.images[img_i], self.N_rand, parallel.counter_seed(self.seed, self.rank, 3, self.it))
         rays = ray.gen_rays(self.H, self.W, self.K, self.poses[img_i, :3, :4], self.near, self.far, pixel_idx)
         target = index.gather_rows(self.images[img_i].reshape(-1, 3), pixel_idx)
         return rays, target
@@ -86,7 +99,7 @@ class Trainer:
             raw = self.coarse.query(rays, z, ref_quirks=self.q)                # updated coarse net, no grad (:270)
             _, _, _, weights, _ = render.composite(raw, z, rays, 0.0, self.white_bkgd)
             if u is None:
-                u = torch.rand(rays.shape[0], self.N, device=self.device, generator=self.gen)
+                u = self.train_uniforms(rays.shape[0])
             _, z_fine = sampling.importance_sample(z, weights, self.N, u=u)
             white_fine = self.white_bkgd if not self.q else False               # Q8
             out["loss_fine"] = self._step_net(self.fine, rays, z_fine, target, white_fine)
@@ -135,10 +148,11 @@ class Trainer:
 
     def state_dict(self):
         """Everything a bit-identical continuation needs: iteration, flat parameters, Adam (m, v) + step counts per
-        state key, and the two host/device RNG streams (image choice, importance uniforms)."""
-        return {"it": self.it, "params": {k: m.params.detach().cpu().clone() for k, m in self._checkpoint_buffers().items()},
-                "adam": self.opt.state_dict(), "rng_numpy": self.rng.bit_generator.state,
-                "rng_torch": self.gen.get_state().clone()}
+        state key.  The random streams are functions of (seed, rank, iteration) (parallel.counter_seed), so there is no
+        RNG state to save and a file written by rank 0 is right for every rank."""
+        return {"it": self.it, "seed": int(self.seed),
+                "params": {k: m.params.detach().cpu().clone() for k, m in self._checkpoint_buffers().items()},
+                "adam": self.opt.state_dict()}
 
     def load_state_dict(self, sd):
         self.it = int(sd["it"])
@@ -153,10 +167,9 @@ class Trainer:
         if "state" not in adam:                                              # round-1 layout: {key: [m, v]}
             adam = {"state": adam, "step_count": {}}
         self.opt.load_state_dict(adam, device=self.device)
-        if "rng_numpy" in sd:
-            self.rng.bit_generator.state = sd["rng_numpy"]
-        if "rng_torch" in sd:
-            self.gen.set_state(torch.as_tensor(sd["rng_torch"], dtype=torch.uint8).cpu())
+        if "seed" in sd and int(sd["seed"]) != int(self.seed):
+            raise ValueError(f"checkpoint was written by a run with seed {int(sd['seed'])}, this trainer has seed {self.seed}: "
+                             "its random streams would not continue the saved run")
 
     @staticmethod
     def _npz_path(path: str) -> str:
@@ -168,15 +181,13 @@ class Trainer:
         also what load() does)."""
         import json
         sd = self.state_dict()
-        arrays = {"it": np.array(sd["it"], dtype=np.int64)}
+        arrays = {"it": np.array(sd["it"], dtype=np.int64), "seed": np.array(sd["seed"], dtype=np.int64)}
         for k, t in sd["params"].items():
             arrays[f"params/{k}"] = t.numpy()
         for k, (m, v) in sd["adam"]["state"].items():
             arrays[f"adam/{k}/m"], arrays[f"adam/{k}/v"] = m.numpy(), v.numpy()
             arrays[f"adam/{k}/steps"] = np.array(sd["adam"]["step_count"].get(k, 0), dtype=np.int64)
         arrays["adam_lr"] = np.array(sd["adam"]["learning_rate"], dtype=np.float64)
-        arrays["rng_numpy_json"] = np.frombuffer(json.dumps(sd["rng_numpy"]).encode(), dtype=np.uint8)
-        arrays["rng_torch"] = sd["rng_torch"].numpy()
         path = self._npz_path(path)
         tmp = path + ".tmp.npz"
         np.savez(tmp, **arrays)
@@ -197,8 +208,7 @@ class Trainer:
                 sd["adam"]["step_count"][name] = int(z[f"adam/{name}/steps"])
         if "adam_lr" in z.files:
             sd["adam"]["learning_rate"] = float(z["adam_lr"])
-        if "rng_numpy_json" in z.files:
-            sd["rng_numpy"] = json.loads(bytes(z["rng_numpy_json"]).decode())
-            sd["rng_torch"] = torch.from_numpy(z["rng_torch"].copy())
+        if "seed" in z.files:
+            sd["seed"] = int(z["seed"])
         self.load_state_dict(sd)
         return sd["it"]

@@ -34,10 +34,14 @@ def layer_shapes(n_layers=8, width=256, cin=63, cdir=27, skips=(4,), use_viewdir
 
 class NeRF:
     """Same constructor arguments as `mlx_nerf/models/NeRF.py:160-199`.  Initialisation is
-    mlx.nn.Linear's: weight and bias ~ U(-1/sqrt(in), 1/sqrt(in)) (seeded numpy stream)."""
+    mlx.nn.Linear's: weight and bias ~ U(-1/sqrt(in), 1/sqrt(in)) (seeded numpy stream).
+    precision (ours): 16 = bf16 MFMA operands with fp32 accumulate (the benchmarked mode), 32 = the reference's own
+    float32 arithmetic on the fp32 MFMA (8 x 256 view model only).  It is part of the model (`nerf_mlp_arch.precision`):
+    weight image, workspaces and every launch of this object use it; models of both kinds can be used side by side."""
 
     def __init__(self, n_layers=8, width_layers=256, channel_input=3, channel_input_views=3, channel_output=4,
-                 list_skip_connection_layers=[4], is_use_view_directions=False, device="cuda", seed: Optional[int] = None):
+                 list_skip_connection_layers=[4], is_use_view_directions=False, device="cuda", seed: Optional[int] = None,
+                 precision: int = 16):
         self.D, self.W = n_layers, width_layers
         self.channel_input_pos, self.channel_input_dir = channel_input, channel_input_views
         self.list_skip_connection_layers = list(list_skip_connection_layers)
@@ -48,7 +52,10 @@ class NeRF:
         self.n_params = sum(o * i + o for _, o, i in self.shapes)
         self.arch = N.MlpArch(n_layers, width_layers, channel_input, channel_input_views,
                               self.list_skip_connection_layers[0] if len(self.list_skip_connection_layers) == 1 else -1,
-                              int(bool(is_use_view_directions)), channel_output)
+                              int(bool(is_use_view_directions)), channel_output, int(precision))
+        if precision not in (16, 32):
+            raise ValueError("NeRF: precision must be 16 (bf16 MFMA operands) or 32 (fp32 MFMA)")
+        self.precision = int(precision)
         self.out_dim = 4 if is_use_view_directions else channel_output
         rng = np.random.default_rng(seed)
         chunks = []
@@ -61,7 +68,6 @@ class NeRF:
         self._packed = None
         self._dirty = True
         self._packed_version = -1           # params._version the packed image was built from
-        self._packed_prec = -1              # "mlp_precision" in effect when it was packed
         self._ws: Dict[str, torch.Tensor] = {}
         self.name: Optional[str] = None     # stable key for optimiser state / checkpoints ("coarse", "fine", ...)
         self._gen = 0                       # generation of the activation workspace (one per train-mode forward)
@@ -107,17 +113,15 @@ class NeRF:
             nbytes = lib.nerf_mlp_packed_bytes(C.byref(self.arch))
             if nbytes < 0:
                 raise ValueError("libnerf_hip error -3: this NeRF architecture has no HIP kernel (supported: n_layers=8, "
-                                 "width=256, skips=[4] with in=63+27 + view head, or in=40 without view head and out<=4; n_layers=2, "
-                                 "width=64, skips=[] with in=32+16 + view head)")
+                                 "width=256, skips=[4] with in=63+27 + view head [precision 16 or 32], or in=40 without view "
+                                 "head and out<=4; n_layers=2, width=64, skips=[] with in=32+16 + view head)")
             self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         # re-pack when the master parameters changed: kernels that write through raw pointers (Adam) say so with
         # mark_updated(); torch in-place ops on `params` or on the views of parameters() bump the version counter
-        prec = lib.nerf_get_option(b"mlp_precision")     # the fp32 weight streams exist only in an image packed in fp32 mode
-        if self._dirty or self.params._version != self._packed_version or prec != self._packed_prec:
+        if self._dirty or self.params._version != self._packed_version:
             N.check(lib.nerf_mlp_pack(C.byref(self.arch), N.ptr(self.params), N.ptr(self._packed), N.stream()))
             self._dirty = False
             self._packed_version = self.params._version
-            self._packed_prec = prec
         return self._packed
 
     def _begin_train_pass(self, M: int) -> torch.Tensor:
@@ -283,7 +287,7 @@ class NetworkQuery:
         return model.query(rays, z, ref_quirks=self.ref_quirks, train=train)
 
 
-def create_NeRF(args, device="cuda", ref_quirks: bool = True, seed: Optional[int] = 0):
+def create_NeRF(args, device="cuda", ref_quirks: bool = True, seed: Optional[int] = 0, precision: int = 16):
     """Coarse (& fine) models, the query function, one Adam, and the render kwargs
     (`models/NeRF.py:51-158`).  Returns (render_kwargs_train, render_kwargs_test, idx_iter, optimizer);
     in quirk mode the two dicts are the SAME object like upstream (:152)."""
@@ -295,7 +299,7 @@ def create_NeRF(args, device="cuda", ref_quirks: bool = True, seed: Optional[int
     query = NetworkQuery(embed_pos, embed_dir, args.netchunk, ref_quirks)
     mk = lambda d, w, s: NeRF(n_layers=d, width_layers=w, channel_input=ch_pos, channel_output=output_ch,
                               list_skip_connection_layers=[4], channel_input_views=ch_dir,
-                              is_use_view_directions=is_use_dir, device=device, seed=s)
+                              is_use_view_directions=is_use_dir, device=device, seed=s, precision=precision)
     model_coarse = mk(args.netdepth, args.netwidth, seed)
     model_fine = mk(args.netdepth_fine, args.netwidth_fine, None if seed is None else seed + 1) if args.N_importance > 0 else None
     optimizer = Adam(learning_rate=args.lrate, betas=(0.9, 0.999), shared_state=ref_quirks)

@@ -19,17 +19,16 @@ class Embedder:
         self.n_freqs = kw["num_freqs"]
         if not kw["log_sampling"]:
             raise NotImplementedError                                         # embedding.py:51
-        if not kw["include_input"]:
-            raise NotImplementedError("HIP embedder keeps the raw input block (3-d inputs, embedding.py:79)")
+        self.include_input = bool(kw["include_input"])                        # False only for 2-d inputs (embedding.py:79)
         self.freq_mode = 0 if kw.get("ref_quirks", True) else 1
-        self.out_dim = self.in_dim * (1 + 2 * self.n_freqs)
+        self.out_dim = self.in_dim * ((1 if self.include_input else 0) + 2 * self.n_freqs)
 
     def embed(self, inputs: torch.Tensor) -> torch.Tensor:
         x = N.f32(inputs)
         M = x.shape[0]
-        out = torch.empty(M, self.out_dim, dtype=torch.float32, device=x.device)
+        out = torch.empty(M, self.in_dim * (1 + 2 * self.n_freqs), dtype=torch.float32, device=x.device)
         N.check(N.lib().nerf_encode_freq(N.ptr(x), M, self.in_dim, self.n_freqs, self.freq_mode, N.ptr(out), N.stream()))
-        return out
+        return out if self.include_input else out[:, self.in_dim:].contiguous()    # the kernel always writes the raw block first
 
 
 def get_embedder(n_freqs: int, /, n_input_dims: int = 3, ref_quirks: bool = True):

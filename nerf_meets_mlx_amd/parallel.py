@@ -55,6 +55,22 @@ def rank_seed(seed: int, rank: int, stream: int = 0) -> int:
     return (seed * 1000003 + rank * 7919 + stream * 104729) & ((1 << 63) - 1)
 
 
+def counter_seed(seed: int, rank: int, stream: int, it: int) -> int:
+    """Stateless 63-bit seed for (run seed, rank, stream, iteration): the trainers draw everything random of iteration
+    `it` from generators seeded with this, so that a run resumed from a checkpoint at iteration `it` -- on any rank,
+    whoever wrote the file -- continues exactly like the uninterrupted one; no RNG state needs saving.
+    (splitmix64 finaliser over an odd-multiplier combination of the four counters: ~1 us of host time.)"""
+    m = (1 << 64) - 1
+    x = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xBF58476D1CE4E5B9 + int(stream) * 0x94D049BB133111EB
+         + int(it) * 0xD6E8FEB86659FD93 + 0x2545F4914F6CDD1D) & m
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & m
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & m
+    x ^= x >> 31
+    return x >> 1
+
+
 def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks of the flat gradient buffer; identity for one process."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -80,6 +80,8 @@ def render_rays_fused(rays, network_coarse, network_fine, n_depth_samples, N_imp
     if with_coarse:
         ret = {"rgb_coarse": f(B, 3), "disp_coarse": f(B), "acc_coarse": f(B), "z_vals": f(B, n), "weights": f(B, n)}
     fine = network_fine if network_fine else network_coarse
+    if getattr(fine, "precision", 16) != getattr(network_coarse, "precision", 16):
+        raise ValueError("render_rays_fused: coarse and fine networks must have the same precision (one nerf_mlp_arch per call)")
     N.check(N.lib().nerf_render_rays_fused(
         C.byref(network_coarse.arch), N.ptr(network_coarse.packed()), N.ptr(fine.packed()), N.ptr(rays), B, n, Nn,
         N.ptr(u) if Nn > 0 else None, 0 if ref_quirks else 1, int(bool(white_bkgd)), N.ptr(ws), N.ptr(rgb), N.ptr(disp),

@@ -41,9 +41,11 @@ def add_noise_z(z_vals: torch.Tensor, strength: float = 1.0, t_rand: Optional[to
     z = N.f32(z_vals)
     if t_rand is None:
         t_rand = torch.rand_like(z)                                             # mx.random.uniform (:17)
+    else:                                                                       # the kernel reads one uniform per depth:
+        t_rand = N.f32(t_rand, z.device).expand_as(z).contiguous()              # broadcast like the reference's multiply (:29); a wrong shape raises
     n = z.shape[-1]
     out = torch.empty_like(z)
-    N.check(N.lib().nerf_add_noise_z(N.ptr(z), N.ptr(N.f32(t_rand)), z.numel() // n, n, float(strength), N.ptr(out),
+    N.check(N.lib().nerf_add_noise_z(N.ptr(z), N.ptr(t_rand), z.numel() // n, n, float(strength), N.ptr(out),
                                      N.stream()))
     return out
 

@@ -1,6 +1,8 @@
 """N>1 path on the real device: two ranks (gloo transport, both on cuda:0 -- RCCL refuses two ranks on one GPU)
 run the HIP Trainer; after every step all ranks must hold bit-identical parameters (same summed gradients,
-same Adam), and their rays must differ (disjoint per-rank streams)."""
+same Adam), and their rays must differ (disjoint per-rank streams).  Resume: rank 0 alone writes the checkpoint
+(entrypoints/test_nerf.py), every rank loads it, and the continued run must land on the uninterrupted one bit for bit
+with every rank still on its OWN random streams (they are functions of seed, rank and iteration)."""
 import os
 import socket
 
@@ -15,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     import torch.distributed as dist
@@ -40,15 +42,41 @@ def _worker(rank, world, port, q):
     ok = all(torch.equal(ps[0], t) for t in ps) and all(torch.equal(pf[0], t) for t in pf)
     differ = not torch.equal(rs[0], rs[1])
     frame_ok = (frame is None) if rank else (tuple(frame.shape) == (16, 16, 3) and bool(torch.isfinite(frame).all()))
-    q.put((rank, ok, differ, frame_ok, float(out["loss_coarse"])))
+    # ---- multi-rank resume: 2 iterations, rank 0 saves, ALL ranks load, 2 more == 4 uninterrupted
+    mk = lambda: Trainer(imgs, poses, K, N_rand=64, n_depth_samples=64, N_importance=128, seed=4, device="cuda")
+    full = mk()
+    for _ in range(4):
+        full.train_step()
+    part = mk()
+    for _ in range(2):
+        part.train_step()
+    path = os.path.join(tmp, "ck.npz")
+    if rank == 0:
+        part.save(path)
+    parallel.barrier()
+    res = mk()
+    assert res.load(path) == 2
+    r_res, _ = res.sample_batch()
+    r_part, _ = part.sample_batch()
+    own_stream = torch.equal(r_res, r_part)                 # the resumed rank draws what ITS uninterrupted self would draw
+    rs2 = [torch.zeros_like(r_res) for _ in range(world)]
+    dist.all_gather(rs2, r_res)
+    differ2 = not torch.equal(rs2[0], rs2[1])               # ... and not what rank 0 draws
+    u_same = torch.equal(res.train_uniforms(8), part.train_uniforms(8)) and res.image_choice() == part.image_choice()
+    for _ in range(2):
+        res.train_step()
+    torch.cuda.synchronize()
+    resume_ok = (own_stream and differ2 and u_same and torch.equal(res.coarse.params, full.coarse.params)
+                 and torch.equal(res.fine.params, full.fine.params))
+    q.put((rank, ok, differ, frame_ok and resume_ok, float(out["loss_coarse"])))
     dist.destroy_process_group()
 
 
-def test_two_ranks_keep_identical_weights():
+def test_two_ranks_keep_identical_weights(tmp_path):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=280) for _ in range(world)]

@@ -25,7 +25,7 @@ DEV = "cuda"
 def _need_gpu():
     assert torch.cuda.is_available(), "GPU tests need a ROCm device"
     from nerf_meets_mlx_amd import _native
-    assert _native.lib().nerf_abi_version() == 2        # fails loudly if the .so is missing
+    assert _native.lib().nerf_abi_version() == 3        # fails loudly if the .so is missing
 
 
 def _relmax(a, b):

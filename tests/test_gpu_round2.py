@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _need_gpu():
     assert torch.cuda.is_available(), "GPU tests need a ROCm device"
     from nerf_meets_mlx_amd import _native
-    assert _native.lib().nerf_abi_version() == 2
+    assert _native.lib().nerf_abi_version() == 3
 
 
 def _relmax(a, b):
@@ -50,10 +50,10 @@ def _rays(B, seed):
     return O.pack_rays(o, d, 2.0, 6.0)
 
 
-def _model_pair(seed=0, scale=1.0):
+def _model_pair(seed=0, scale=1.0, precision=16):
     from nerf_meets_mlx_amd.models.NeRF import NeRF
     arch = O.NerfArch()
-    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=seed)
+    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=seed, precision=precision)
     flat = O.flatten_params(arch, O.init_params(arch, seed))
     assert torch.equal(m.params.cpu(), flat)
     if scale != 1.0:
@@ -138,26 +138,21 @@ def test_mlp_every_layer_and_mask_aligned_backward(B, n):
 # ------------------------------------------------------------------------------ fp32 reference-precision mode
 @pytest.mark.parametrize("quirk", [True, False])
 def test_fp32_mode_forward_matches_fp32_oracle(quirk):
-    """nerf_set_option("mlp_precision", 32): the fused chain on v_mfma_f32_32x32x2_f32 with fp32 operands -- the
+    """NeRF(precision=32) (nerf_mlp_arch.precision): the fused chain on v_mfma_f32_32x32x2_f32 with fp32 operands -- the
     reference's own arithmetic (MLX computes in float32).  <= 1e-4 of the output scale against the fp32 oracle
     (fp32 accumulation-order noise over 12 layers; the encodings use the hardware sin with fp32 range reduction,
     <= 2e-6 absolute per channel)."""
-    from nerf_meets_mlx_amd import _native
-    _native.check(_native.lib().nerf_set_option(b"mlp_precision", 32))
-    try:
-        m, arch, flat = _model_pair(1, 1.5)
-        p = O.unflatten_params(arch, flat)
-        for B, n in [(3, 64), (5, 192), (1, 7), (100, 64)]:
-            rays = _rays(B, 10 + B)
-            z = torch.sort(torch.rand(B, n) * 4 + 2, -1).values
-            raw = m.query(rays.to(DEV), z.to(DEV), ref_quirks=quirk).cpu()
-            o, d, _, _, vd = O.decompose_ray_batch(rays)
-            pos = o[:, None, :] + z[:, :, None] * d[:, None, :]
-            ref = O.run_model(arch, p, pos, vd, ref_quirks=quirk)
-            assert raw.shape == (B, n, 4)
-            assert _relmax(raw, ref) < 1e-4, (B, n, _relmax(raw, ref))
-    finally:
-        _native.check(_native.lib().nerf_set_option(b"mlp_precision", 16))
+    m, arch, flat = _model_pair(1, 1.5, precision=32)
+    p = O.unflatten_params(arch, flat)
+    for B, n in [(3, 64), (5, 192), (1, 7), (100, 64)]:
+        rays = _rays(B, 10 + B)
+        z = torch.sort(torch.rand(B, n) * 4 + 2, -1).values
+        raw = m.query(rays.to(DEV), z.to(DEV), ref_quirks=quirk).cpu()
+        o, d, _, _, vd = O.decompose_ray_batch(rays)
+        pos = o[:, None, :] + z[:, :, None] * d[:, None, :]
+        ref = O.run_model(arch, p, pos, vd, ref_quirks=quirk)
+        assert raw.shape == (B, n, 4)
+        assert _relmax(raw, ref) < 1e-4, (B, n, _relmax(raw, ref))
 
 
 def test_fp32_mode_render_rays_eval_end_to_end():
@@ -165,96 +160,86 @@ def test_fp32_mode_render_rays_eval_end_to_end():
     compositing, rendering/render.py:164-241) in fp32 mode against the fp32 oracle on the same rays and uniforms:
     rgb / acc within 5e-4 absolute (bf16 mode: 3e-2), the integer bin indices of the importance sampler -- hence z_fine --
     identical except where a uniform lands within float32 noise of a CDF step."""
-    from nerf_meets_mlx_amd import _native
     from nerf_meets_mlx_amd.models.NeRF import NeRF
     from nerf_meets_mlx_amd.rendering import render
-    _native.check(_native.lib().nerf_set_option(b"mlp_precision", 32))
-    try:
-        arch = O.NerfArch()
-        mc = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=4)
-        mf = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=5)
-        for mm in (mc, mf):
-            mm.load_flat(mm.params * 1.5)
-        B = 1500
-        rays = _rays(B, 21)
-        u = torch.rand(B, 128, generator=torch.Generator().manual_seed(2))
-        out = render.render_rays_fused(rays.to(DEV), mc, mf, 64, 128, u=u.to(DEV), white_bkgd=True, ref_quirks=True,
-                                       with_coarse=True)
-        ref = O.render_rays_eval(arch, O.unflatten_params(arch, mc.params.cpu()), O.unflatten_params(arch, mf.params.cpu()),
-                                 rays, 64, 128, u, white_bkgd=True)
-        assert float((out["rgb_map"].cpu() - ref["rgb_map"]).abs().max()) < 5e-4
-        assert float((out["acc_map"].cpu().reshape(-1) - ref["acc_map"].reshape(-1)).abs().max()) < 5e-4
-        assert float((out["rgb_coarse"].cpu() - ref["rgb_coarse"]).abs().max()) < 5e-4
-    finally:
-        _native.check(_native.lib().nerf_set_option(b"mlp_precision", 16))
+    arch = O.NerfArch()
+    mc = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=4, precision=32)
+    mf = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=5, precision=32)
+    for mm in (mc, mf):
+        mm.load_flat(mm.params * 1.5)
+    B = 1500
+    rays = _rays(B, 21)
+    u = torch.rand(B, 128, generator=torch.Generator().manual_seed(2))
+    out = render.render_rays_fused(rays.to(DEV), mc, mf, 64, 128, u=u.to(DEV), white_bkgd=True, ref_quirks=True,
+                                   with_coarse=True)
+    ref = O.render_rays_eval(arch, O.unflatten_params(arch, mc.params.cpu()), O.unflatten_params(arch, mf.params.cpu()),
+                             rays, 64, 128, u, white_bkgd=True)
+    assert float((out["rgb_map"].cpu() - ref["rgb_map"]).abs().max()) < 5e-4
+    assert float((out["acc_map"].cpu().reshape(-1) - ref["acc_map"].reshape(-1)).abs().max()) < 5e-4
+    assert float((out["rgb_coarse"].cpu() - ref["rgb_coarse"]).abs().max()) < 5e-4
 
 
 def test_fp32_mode_backward_and_training_step():
     """fp32 mode, adjoint: dW / db against torch autograd through the fp32 oracle, rel-L2 <= 1e-3 and rel-max <= 1e-2
     for every tensor (no bf16 anywhere, so no rounding-induced ReLU flips: what remains is fp32 summation order over
     thousands of samples), then three Trainer iterations against the OracleTrainer with losses within 1e-3 relative."""
-    from nerf_meets_mlx_amd import _native
     from nerf_meets_mlx_amd.dataset import synthetic
     from nerf_meets_mlx_amd.engine.trainer import Trainer
-    _native.check(_native.lib().nerf_set_option(b"mlp_precision", 32))
-    try:
-        m, arch, flat = _model_pair(3, 1.5)
-        B, n = 64, 96
-        torch.manual_seed(5)
-        rays = _rays(B, 77)
-        z = torch.sort(torch.rand(B, n) * 4 + 2, -1).values
-        g = torch.randn(B, n, 4)
-        raw = m.query(rays.to(DEV), z.to(DEV), train=True)
-        grads = m.backward(g.to(DEV)).cpu()
-        fl = flat.clone().requires_grad_(True)
-        o, d, _, _, vd = O.decompose_ray_batch(rays)
-        pos = o[:, None, :] + z[:, :, None] * d[:, None, :]
-        out = O.run_model(arch, O.unflatten_params(arch, fl), pos, vd)
-        (out * g).sum().backward()
-        assert _relmax(raw.cpu(), out.detach()) < 1e-4
-        off = 0
-        for name, o_, i_ in arch.layer_shapes():
-            for part, cnt in (("W", o_ * i_), ("b", o_)):
-                a, b = grads[off:off + cnt], fl.grad[off:off + cnt]
-                assert _rel_l2(a, b) < 1e-3 and _relmax(a, b) < 1e-2, (name, part, _rel_l2(a, b), _relmax(a, b))
-                off += cnt
-        # every stored layer (float32 [tile][row][32] stores decoded by nerf_mlp_debug_read) against the oracle's taps:
-        # activations to 1e-4 of the layer's scale, dZ to 1e-3 rel-L2 (a handful of units flip at |z| ~ 1e-7)
-        from nerf_meets_mlx_amd.models.NeRF import debug_layer
-        fl2 = flat.clone().requires_grad_(True)
-        taps = {}
-        out2 = O.run_model(arch, O.unflatten_params(arch, fl2), pos, vd, taps=taps)
-        for t in taps.values():
-            t.retain_grad()
-        (out2 * g).sum().backward()
-        for li, name in enumerate(LAYER_NAMES):
-            act = debug_layer(m, "acts", li).cpu()
-            assert act.shape == taps[name].shape and _relmax(act, taps[name].detach()) < 1e-4, (name, _relmax(act, taps[name].detach()))
-            dz = debug_layer(m, "dz", li).cpu()
-            ref = taps[name].grad if name == "feature" else taps[name].grad * (taps[name].detach() > 0).float()
-            assert _rel_l2(dz, ref) < 1e-3, (name, _rel_l2(dz, ref))
-        pe = debug_layer(m, "acts", 10).cpu()
-        xe = O.embed(pos, vd)
-        assert float((pe[:, :63] - xe[:, :63]).abs().max()) < 2e-6 and float(pe[:, 63].abs().max()) == 0.0
-        # NeRF.forward(x) on embedded rows takes the same fp32 kernels
-        rows = torch.randn(100, 90, generator=torch.Generator().manual_seed(3))
-        got = m.forward(rows.to(DEV)).cpu()
-        assert _relmax(got, O.nerf_forward(arch, O.unflatten_params(arch, flat), rows)) < 1e-4
-        H = W = 24
-        imgs, poses, _, _, K = synthetic.make_dataset(H, W, 3, seed=0, device=DEV)
-        tr = Trainer(imgs, poses, K, N_rand=128, n_depth_samples=64, N_importance=128, seed=4, device=DEV)
-        ot = O.OracleTrainer(arch, 64, 128, seed=4)
-        gen = torch.Generator().manual_seed(3)
-        for it in range(3):
-            r, t = tr.sample_batch()
-            u = torch.rand(128, 128, generator=gen)
-            lh = tr.train_step(r, t, u.to(DEV))
-            lo = ot.step(r[:, 0:3].cpu(), r[:, 3:6].cpu(), t.cpu(), u)
-            assert abs(float(lh["loss_coarse"]) - lo["loss_coarse"]) <= 1e-3 * abs(lo["loss_coarse"]), (it, lh, lo)
-            assert abs(float(lh["loss_fine"]) - lo["loss_fine"]) <= 1e-3 * abs(lo["loss_fine"]), (it, lh, lo)
-        assert _rel_l2(tr.coarse.params.cpu(), ot.pc.detach()) < 1e-4
-    finally:
-        _native.check(_native.lib().nerf_set_option(b"mlp_precision", 16))
+    m, arch, flat = _model_pair(3, 1.5, precision=32)
+    B, n = 64, 96
+    torch.manual_seed(5)
+    rays = _rays(B, 77)
+    z = torch.sort(torch.rand(B, n) * 4 + 2, -1).values
+    g = torch.randn(B, n, 4)
+    raw = m.query(rays.to(DEV), z.to(DEV), train=True)
+    grads = m.backward(g.to(DEV)).cpu()
+    fl = flat.clone().requires_grad_(True)
+    o, d, _, _, vd = O.decompose_ray_batch(rays)
+    pos = o[:, None, :] + z[:, :, None] * d[:, None, :]
+    out = O.run_model(arch, O.unflatten_params(arch, fl), pos, vd)
+    (out * g).sum().backward()
+    assert _relmax(raw.cpu(), out.detach()) < 1e-4
+    off = 0
+    for name, o_, i_ in arch.layer_shapes():
+        for part, cnt in (("W", o_ * i_), ("b", o_)):
+            a, b = grads[off:off + cnt], fl.grad[off:off + cnt]
+            assert _rel_l2(a, b) < 1e-3 and _relmax(a, b) < 1e-2, (name, part, _rel_l2(a, b), _relmax(a, b))
+            off += cnt
+    # every stored layer (float32 [tile][row][32] stores decoded by nerf_mlp_debug_read) against the oracle's taps:
+    # activations to 1e-4 of the layer's scale, dZ to 1e-3 rel-L2 (a handful of units flip at |z| ~ 1e-7)
+    from nerf_meets_mlx_amd.models.NeRF import debug_layer
+    fl2 = flat.clone().requires_grad_(True)
+    taps = {}
+    out2 = O.run_model(arch, O.unflatten_params(arch, fl2), pos, vd, taps=taps)
+    for t in taps.values():
+        t.retain_grad()
+    (out2 * g).sum().backward()
+    for li, name in enumerate(LAYER_NAMES):
+        act = debug_layer(m, "acts", li).cpu()
+        assert act.shape == taps[name].shape and _relmax(act, taps[name].detach()) < 1e-4, (name, _relmax(act, taps[name].detach()))
+        dz = debug_layer(m, "dz", li).cpu()
+        ref = taps[name].grad if name == "feature" else taps[name].grad * (taps[name].detach() > 0).float()
+        assert _rel_l2(dz, ref) < 1e-3, (name, _rel_l2(dz, ref))
+    pe = debug_layer(m, "acts", 10).cpu()
+    xe = O.embed(pos, vd)
+    assert float((pe[:, :63] - xe[:, :63]).abs().max()) < 2e-6 and float(pe[:, 63].abs().max()) == 0.0
+    # NeRF.forward(x) on embedded rows takes the same fp32 kernels
+    rows = torch.randn(100, 90, generator=torch.Generator().manual_seed(3))
+    got = m.forward(rows.to(DEV)).cpu()
+    assert _relmax(got, O.nerf_forward(arch, O.unflatten_params(arch, flat), rows)) < 1e-4
+    H = W = 24
+    imgs, poses, _, _, K = synthetic.make_dataset(H, W, 3, seed=0, device=DEV)
+    tr = Trainer(imgs, poses, K, N_rand=128, n_depth_samples=64, N_importance=128, seed=4, device=DEV, precision=32)
+    ot = O.OracleTrainer(arch, 64, 128, seed=4)
+    gen = torch.Generator().manual_seed(3)
+    for it in range(3):
+        r, t = tr.sample_batch()
+        u = torch.rand(128, 128, generator=gen)
+        lh = tr.train_step(r, t, u.to(DEV))
+        lo = ot.step(r[:, 0:3].cpu(), r[:, 3:6].cpu(), t.cpu(), u)
+        assert abs(float(lh["loss_coarse"]) - lo["loss_coarse"]) <= 1e-3 * abs(lo["loss_coarse"]), (it, lh, lo)
+        assert abs(float(lh["loss_fine"]) - lo["loss_fine"]) <= 1e-3 * abs(lo["loss_fine"]), (it, lh, lo)
+    assert _rel_l2(tr.coarse.params.cpu(), ot.pc.detach()) < 1e-4
 
 
 # ------------------------------------------------------------------------------ PSNR parity over a training run
@@ -378,7 +363,8 @@ def _mini_trainer(kind="nerf", shared=True, seed=4):
 def test_checkpoint_npz_roundtrip_continues(tmp_path, kind, shared):
     """save() mid-training -> load() into a FRESH trainer: the restored state is BIT-identical to the saved one --
     parameters, Adam (m, v) per state key (shared, or coarse / fine, or mlp / tables), step counts (the NGP loop uses
-    bias correction), iteration (LR schedule) and both RNG streams (the next batch is the same rays, bit for bit) --
+    bias correction) and iteration (LR schedule; it is also the whole RNG state: every random draw of iteration `it` is a
+    function of (seed, rank, it), so the next batch is the same rays, bit for bit) --
     and training continues on the same trajectory: BIT-identical parameters after two more iterations for the 8 x 256
     trainer (its kernels are deterministic since the split-K partial tiles are reduced in a fixed order; the reported
     loss scalar is still an atomic sum, compared at 1e-5), fp32 summation-noise level for the hash-grid trainer (its
@@ -402,8 +388,7 @@ def test_checkpoint_npz_roundtrip_continues(tmp_path, kind, shared):
     ra, ta = a.sample_batch()
     rb, tb = b.sample_batch()
     assert torch.equal(ra, rb) and torch.equal(ta, tb)                     # same image, same pixels: RNG streams restored
-    ua = torch.rand(4, device=DEV, generator=a.gen); ub = torch.rand(4, device=DEV, generator=b.gen)
-    assert torch.equal(ua, ub)
+    assert torch.equal(a.train_uniforms(4), b.train_uniforms(4)) and a.image_choice() == b.image_choice()
     cont = [a.train_step() for _ in range(2)]
     again = [b.train_step() for _ in range(2)]
     for x, y in zip(cont, again):
@@ -473,23 +458,22 @@ def test_stale_activation_and_stale_weight_guards():
     # option validation and the refusals of the new entry points
     from nerf_meets_mlx_amd import _native as NV
     L = NV.lib()
-    assert L.nerf_set_option(b"mlp_precision", 8) == -3 and L.nerf_set_option(b"ring_split", 3) == -3
-    assert L.nerf_get_option(b"mlp_precision") == 16 and L.nerf_get_option(b"ring_split") == 1
+    assert L.nerf_set_option(b"mlp_precision", 32) == -3 and b"nerf_mlp_arch.precision" in L.nerf_last_error()   # ABI 3: not an option
+    assert L.nerf_set_option(b"ring_split", 3) == -3
+    assert L.nerf_get_option(b"mlp_precision") == -1 and L.nerf_get_option(b"ring_split") == 1
     zz = torch.rand(4, 8, device=DEV)
     assert L.nerf_add_noise_z(NV.ptr(zz), NV.ptr(zz), 4, 8, 1.0, NV.ptr(zz), None) == -2        # in place is refused
-    # a launch in fp32 mode on a weight image that was packed in bf16 mode fails loudly instead of using stale streams
+    # precision belongs to the model: an arch with an unknown precision, or fp32 for a model without fp32 kernels, is refused
     import ctypes as C
-    m3, _, _ = _model_pair(6)
-    packed = m3.packed()                                   # packed with mlp_precision == 16
-    L.nerf_set_option(b"mlp_precision", 32)
-    try:
-        out = torch.empty(8, 64, 4, device=DEV)
-        rc = L.nerf_query_fused(C.byref(m3.arch), NV.ptr(packed), NV.ptr(rays), NV.ptr(z), 8, 64, 0, NV.ptr(out), None, NV.stream())
-        assert rc == -3 and b"packed" in L.nerf_last_error()
-        ok = m3.query(rays, z)                             # the host mirror re-packs when the mode changed
-        assert torch.isfinite(ok).all()
-    finally:
-        L.nerf_set_option(b"mlp_precision", 16)
+    bad = NV.MlpArch(8, 256, 63, 27, 4, 1, 4, 24)
+    assert L.nerf_mlp_packed_bytes(C.byref(bad)) == -1
+    img32 = NV.MlpArch(8, 256, 40, 0, 4, 0, 3, 32)
+    assert L.nerf_mlp_packed_bytes(C.byref(img32)) == -1
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    with pytest.raises(ValueError):
+        NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=0, precision=8)
+    with pytest.raises(ValueError):
+        NeRF(channel_input=40, channel_output=3, is_use_view_directions=False, device=DEV, seed=0, precision=32).packed()
     # gather_rows: out-of-range indices never read, they give NaN rows
     src = torch.arange(12, dtype=torch.float32, device=DEV).reshape(4, 3)
     got = index.gather_rows(src, torch.tensor([0, 3, 4, -1], device=DEV))

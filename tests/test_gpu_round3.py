@@ -1,0 +1,316 @@
+"""Round-3 GPU tests.
+
+(1) The HIP path against fixtures produced by the reference's OWN source (rendering/render.py, models/embedding.py,
+    models/NeRF.py, encoding/*.py, ops/*.py, sampling/*.py executed over a numpy `mx` shim in the build container:
+    tests/golden/make_golden_mx.py).  fp32 models (NeRF(precision=32), the reference's arithmetic) are held to
+    float32 noise, bf16 models to the bf16 tolerances of tests/test_gpu_parity.py.
+(2) Precision is part of the model (ABI 3): a bf16 and an fp32 model interleaved on two streams.
+(3) The pixel permutation as a SAMPLER (uniformity / independence), next to numpy's choice(replace=False).
+(4) The north-star PSNR statement as a paired ensemble cut (bf16 arm vs fp32 arm on identical batches).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from nerf_meets_mlx_amd import _native
+    assert _native.lib().nerf_abi_version() == 3
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    with open(os.path.join(golden_dir, "ref_mx_meta.json")) as fp:
+        return json.load(fp)
+
+
+def _npz(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def D(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(got, want, atol, rtol=0.0):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    np.testing.assert_allclose(got, np.asarray(want), atol=atol, rtol=rtol, equal_nan=True)
+
+
+def _flat_from_seed(layers, seed, checksum, alpha=(1.0, 0.0)):
+    rng = np.random.default_rng(seed)
+    chunks, tot = [], 0.0
+    for name, o, i in layers:
+        k = 1.0 / np.sqrt(i)
+        w = rng.uniform(-k, k, size=(o, i)).astype(np.float32)
+        b = rng.uniform(-k, k, size=(o,)).astype(np.float32)
+        tot += float(np.abs(w.astype(np.float64)).sum() + np.abs(b.astype(np.float64)).sum())
+        if name == "alpha":
+            w = w * np.float32(alpha[0]); b = b * np.float32(alpha[0]) + np.float32(alpha[1])
+        chunks += [w.reshape(-1), b]
+    assert abs(tot - checksum) <= 1e-9 * checksum
+    return torch.from_numpy(np.concatenate(chunks))
+
+
+def _model(ctor, layers, seed, checksum, precision, alpha=(1.0, 0.0)):
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    m = NeRF(n_layers=ctor["n_layers"], width_layers=ctor["width_layers"], channel_input=ctor["channel_input"],
+             channel_input_views=ctor["channel_input_views"], channel_output=ctor["channel_output"],
+             list_skip_connection_layers=ctor["list_skip_connection_layers"],
+             is_use_view_directions=ctor["is_use_view_directions"], device=DEV, seed=0, precision=precision)
+    assert [list(t) for t in m.shapes] == [list(l) for l in layers]             # our constructor == the reference's shapes
+    m.load_flat(_flat_from_seed(layers, seed, checksum, alpha))
+    return m
+
+
+# ------------------------------------------------------------------------------------------------ a13
+def test_raw2outputs_vs_reference_source_fixture(golden_dir, meta):
+    from nerf_meets_mlx_amd.rendering import render
+    g = _npz(golden_dir, "ref_mx_raw2outputs.npz")
+    for c in meta["raw2outputs"]["cases"]:
+        t = c["tag"]
+        rgb, disp, acc, w, depth = render.raw2outputs(D(g[f"{t}_raw"]), D(g[f"{t}_z"]), D(g[f"{t}_d"]), 0, c["white_bkgd"])
+        assert tuple(w.shape) == g[f"{t}_weights"].shape and tuple(disp.shape) == g[f"{t}_disp"].shape      # [B,n,1], [B,1]
+        sc = max(1.0, float(np.nanmax(np.abs(g[f"{t}_weights"]))))
+        close(w, g[f"{t}_weights"], atol=3e-6 * sc, rtol=1e-4)            # exp(+large) for negative sigma: relative
+        close(acc, g[f"{t}_acc"], atol=2e-5 * sc, rtol=1e-4)
+        close(rgb, g[f"{t}_rgb"], atol=2e-5 * sc, rtol=2e-4)
+        close(depth, g[f"{t}_depth"], atol=2e-5 * sc, rtol=2e-4)
+        assert np.array_equal(np.isnan(disp.cpu().numpy()), np.isnan(g[f"{t}_disp"]))                       # Q11
+    rgb, disp, acc, w, depth = render.raw2outputs(D(g["noise_raw"]), D(g["noise_z"]), D(g["noise_d"]), meta["raw2outputs"]["noise_std"],
+                                                  True, noise=D(g["noise_noise"]))
+    close(w, g["noise_weights"], atol=3e-6, rtol=1e-4)
+    close(rgb, g["noise_rgb"], atol=2e-5, rtol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ a9 a10 a23 a24
+def test_encodings_vs_reference_source_fixture(golden_dir, meta):
+    from nerf_meets_mlx_amd.encoding.identity import IdentityEncoding
+    from nerf_meets_mlx_amd.encoding.sinusoidal import SinusoidalEncoding
+    from nerf_meets_mlx_amd.encoding.spherical_harmonics import SphericalHarmonicsEncoding
+    from nerf_meets_mlx_amd.models import embedding
+    g = _npz(golden_dir, "ref_mx_encodings.npz")
+    x3, dirs = D(g["x3"]), D(g["dirs"])
+    f10, d10 = embedding.get_embedder(10)
+    f4, d4 = embedding.get_embedder(4)
+    f2, d2 = embedding.get_embedder(6, n_input_dims=2)
+    fid, did = embedding.get_embedder(-1)
+    e = meta["embedder"]
+    assert (d10, d4, d2, did) == (e["out_dim_10"], e["out_dim_4"], e["out_dim_2d_6"], e["out_dim_identity"])
+    close(f10(x3), g["emb10"], atol=4e-6)                      # |arg| <= 81 * 4: cosf / sinf with fp32 range reduction
+    close(f4(dirs), g["emb4"], atol=1e-6)
+    close(f2(D(g["x2"])), g["emb2d_6"], atol=2e-6)             # 2-d inputs: no raw-input block (embedding.py:79)
+    assert torch.equal(fid(x3), x3)
+    close(embedding.embed(D(g["embed_pos"]), f10, D(g["embed_dir"]), f4), g["embed_out"], atol=4e-6)
+    close(embedding.embed(D(g["embed_pos"]), f10, None, None), g["embed_out_nodir"], atol=4e-6)
+    s = meta["sinusoidal"]
+    enc = SinusoidalEncoding(2, 10, 0.0, 8.0, False)
+    assert enc.get_out_dim() == s["img"]["out_dim"]
+    got = enc(D(g["sin_xi"]))
+    close(got[:, :5], g["sin_img"][:, :5], atol=2e-4)          # small arguments
+    close(got, g["sin_img"], atol=1e-2)                        # |arg| up to 1e5: one fp32 ulp of the argument is 8e-3 rad
+    enc2 = SinusoidalEncoding(3, 4, is_include_input=True)
+    assert enc2.get_out_dim() == s["inc"]["out_dim"]
+    close(enc2(x3), g["sin_inc"], atol=3e-6)
+    enc3 = SinusoidalEncoding(3, 5, -1.0, 2.5, False)
+    close(enc3(x3), g["sin_frac"], atol=6e-6)
+    for deg in range(5):
+        sh = SphericalHarmonicsEncoding(3, deg)
+        close(sh(dirs), g[f"sh{deg}"], atol=2e-6)
+    assert torch.equal(IdentityEncoding(3)(x3), x3)
+
+
+# ------------------------------------------------------------------------------------------------ a11 a12
+@pytest.mark.parametrize("tag,precision,tol", [("view", 32, 1e-4), ("view", 16, 1.5e-2), ("image", 16, 1.5e-2), ("ngp", 16, 1.5e-2)])
+def test_mlp_forward_vs_reference_source_fixture(golden_dir, meta, tag, precision, tol):
+    """NeRF.forward (models/NeRF.py:201-243) on rows the reference's own class produced outputs for.  fp32 model: 1e-4
+    of the output scale (float32 summation order over 12 layers); bf16 models: 1.5e-2 (bf16 operands, 8 mantissa bits,
+    random walk over the layers; against the bf16-EMULATING oracle the same kernels are at 1e-2, test_gpu_parity)."""
+    g = _npz(golden_dir, "ref_mx_mlp.npz")
+    net = meta["mlp"]["nets"][tag]
+    m = _model(net["ctor"], net["layers"], net["seed"], net["checksum"], precision)
+    out = m.forward(D(g[f"{tag}_x"]))
+    want = g[f"{tag}_out"]
+    assert tuple(out.shape) == want.shape
+    assert float(np.abs(out.cpu().numpy() - want).max() / np.abs(want).max()) < tol
+
+
+@pytest.mark.parametrize("precision,tol", [(32, 1e-4), (16, 1.5e-2)])
+def test_run_model_vs_reference_source_fixture(golden_dir, meta, precision, tol):
+    from nerf_meets_mlx_amd.models import embedding
+    from nerf_meets_mlx_amd.models.NeRF import run_model
+    g = _npz(golden_dir, "ref_mx_mlp.npz")
+    net = meta["mlp"]["nets"]["view"]
+    m = _model(net["ctor"], net["layers"], net["seed"], net["checksum"], precision)
+    f10, _ = embedding.get_embedder(10)
+    f4, _ = embedding.get_embedder(4)
+    out = run_model(D(g["run_pos"]), f10, D(g["run_dir"]), f4, m, netchunk=meta["mlp"]["run_model_netchunk"])
+    assert tuple(out.shape) == g["run_out"].shape
+    assert float(np.abs(out.cpu().numpy() - g["run_out"]).max() / np.abs(g["run_out"]).max()) < tol
+    with pytest.raises(AssertionError):                                         # models/NeRF.py:31
+        run_model(D(g["run_pos"]).reshape(-1, 3), f10, D(g["run_dir"]), f4, m)
+
+
+# ------------------------------------------------------------------------------------------------ a2 a4 a5 a6 a7 a20 a25
+def test_sampling_rays_metric_pose_vs_reference_source_fixture(golden_dir, meta):
+    from nerf_meets_mlx_amd import sampling
+    from nerf_meets_mlx_amd.ops import metric
+    from nerf_meets_mlx_amd.ops.pose import pose_spherical
+    from nerf_meets_mlx_amd.rendering import ray, render
+    from nerf_meets_mlx_amd.sampling import linear_disparity, uniform
+    g = _npz(golden_dir, "ref_mx_misc.npz")
+    near, far = D(g["near"]), D(g["far"])
+    assert torch.equal(uniform.sample_z(near, far, 64).cpu(), torch.from_numpy(g["z_uniform_64"]))          # same fp32 op sequence
+    assert torch.equal(uniform.sample_z(near, far, 5).cpu(), torch.from_numpy(g["z_uniform_5"]))
+    zl = linear_disparity.sample_z(near, far, 64).cpu().numpy()
+    close(zl, g["z_lindisp_64"], atol=0, rtol=2e-6)
+    assert np.all(zl[:, 0] == 0) and np.all(zl[:, -1] == 0)                                                 # Q12
+    z = D(g["z_uniform_64"])
+    assert sampling.add_noise_z(z, 0.0) is z                                                                # :13-14 returns z_vals itself
+    n = meta["sampling"]["ndc"]
+    no, nd = ray.ndc_rays(n["H"], n["W"], n["focal"], n["near"], D(g["ndc_o_in"]), D(g["ndc_d_in"]))
+    close(no, g["ndc_o"], atol=2e-6, rtol=2e-5); close(nd, g["ndc_d"], atol=2e-6, rtol=2e-5)
+    o, d, nr, fr, vd, ft = render.decompose_ray_batch(D(g["rays_linear"]))
+    assert ft is None and tuple(nr.shape) == (6, 1)
+    for got, key in ((o, "dec_o"), (d, "dec_d"), (nr, "dec_near"), (fr, "dec_far"), (vd, "dec_viewdirs")):
+        assert np.array_equal(got.cpu().numpy(), g[key])
+    close(metric.MSE()(D(g["metric_a"]), D(g["metric_b"])), g["mse"], atol=0, rtol=2e-6)
+    close(metric.PSNR()(D(g["metric_a"]), D(g["metric_b"])), g["psnr"], atol=0, rtol=2e-6)
+    for args, want in zip(g["pose_args"], g["pose_out"]):
+        close(np.asarray(pose_spherical(*[float(a) for a in args])), want, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ create_NeRF, a14 a18 a19
+def _render_kwargs(meta, precision):
+    """create_NeRF exactly as the fixture's generator called the reference's (args from config_parser defaults + the
+    same overrides), then the fixture's weights loaded into the two networks."""
+    from nerf_meets_mlx_amd import config_parser as C
+    from nerf_meets_mlx_amd.models.NeRF import create_NeRF
+    r = meta["render"]
+    args = C.config_parser().parse_args(args=[])
+    args.use_viewdirs = True; args.white_bkgd = True; args.dataset_type = "blender"; args.N_importance = r["N_importance"]
+    args.n_depth_samples = r["n_depth_samples"]; args.netchunk = r["netchunk"]; args.lindisp = False
+    kw_train, kw_test, idx_iter, opt = create_NeRF(args, device=DEV, precision=precision)
+    c = meta["create_NeRF"]
+    assert kw_test is kw_train and set(kw_train.keys()) == set(c["keys"]) and idx_iter == c["idx_iter"]      # Q5 alias
+    assert kw_train["render_rays_func"].__name__ == c["render_rays_func"]
+    for k, v in c["values"].items():
+        assert kw_train[k] == v, (k, kw_train[k], v)
+    assert opt.learning_rate == c["optimizer"]["learning_rate"] and list(opt.betas) == c["optimizer"]["betas"]
+    layers = [tuple(l) for l in r["layers"]]
+    for name in ("coarse", "fine"):
+        kw_train[f"network_{name}"].load_flat(_flat_from_seed(layers, r["seeds"][name], r["checksum"][name], r["alpha_scale_bias"][name]))
+    kw_train.update({"near": r["near"], "far": r["far"]})
+    return kw_train, r
+
+
+@pytest.mark.parametrize("precision,tol_raw,tol_w", [(32, 1e-4, 2e-5), (16, 2e-2, 1.5e-2)])
+def test_render_rays_vs_reference_source_fixture(golden_dir, meta, precision, tol_raw, tol_w):
+    from nerf_meets_mlx_amd.rendering import render
+    g = _npz(golden_dir, "ref_mx_render.npz")
+    kw, r = _render_kwargs(meta, precision)
+    call = {k: v for k, v in kw.items() if k not in ("use_viewdirs", "is_test", "ndc", "near", "far", "render_rays_func")}
+    ret = render.render_rays(D(g["rr_rays"]), retraw=True, **call)
+    assert sorted(ret.keys()) == sorted(["raw", "rgb_map", "disp_map", "acc_map", "rgb_coarse", "disp_coarse", "acc_coarse", "z_vals", "weights"])
+    assert torch.equal(ret["z_vals"].cpu(), torch.from_numpy(g["rr_z_vals"]))
+    assert tuple(ret["weights"].shape) == (40, 64, 1) and tuple(ret["disp_map"].shape) == (40, 1)
+    assert float(np.abs(ret["raw"].cpu().numpy() - g["rr_raw"]).max() / np.abs(g["rr_raw"]).max()) < tol_raw
+    close(ret["weights"], g["rr_weights"], atol=tol_w)
+    close(ret["rgb_map"], g["rr_rgb_map"], atol=tol_w); close(ret["acc_map"], g["rr_acc_map"], atol=tol_w)
+
+
+@pytest.mark.parametrize("precision,tol", [(32, 1e-4), (16, 2e-2)])
+def test_render_rays_eval_and_render_vs_reference_source_fixture(golden_dir, meta, precision, tol):
+    """render_rays_eval (a18) and render() (a19: get_rays -> packing -> ragged chunks -> reshape) against what the
+    reference's own render.py returned for the same weights, rays and uniforms."""
+    from nerf_meets_mlx_amd.rendering import render
+    g = _npz(golden_dir, "ref_mx_render.npz")
+    kw, r = _render_kwargs(meta, precision)
+    call = {k: v for k, v in kw.items() if k not in ("use_viewdirs", "is_test", "ndc", "near", "far", "render_rays_func")}
+    ret = render.render_rays_eval(D(g["rr_rays"]), u=D(g["re_u"]), **call)
+    close(ret["rgb_coarse"], g["re_rgb_coarse"], atol=tol)
+    close(ret["rgb_map"], g["re_rgb_map"], atol=tol); close(ret["acc_map"], g["re_acc_map"], atol=tol)
+    H, W = (int(v) for v in g["render_HW"])
+    rgb, disp, acc, extras = render.render(H, W, g["render_K"], chunk=int(g["render_chunk"]), c2w=g["render_c2w"], u=D(g["render_u"]), **kw)
+    assert tuple(rgb.shape) == (H, W, 3) and tuple(disp.shape) == (H, W, 1) and tuple(acc.shape) == (H, W, 1)
+    close(rgb, g["render_rgb"], atol=tol); close(acc, g["render_acc"], atol=tol)
+    assert set(extras.keys()) == set(meta["render"]["extras_keys"])
+    assert tuple(extras["weights"].shape) == (H, W, 64, 1) and tuple(extras["z_vals"].shape) == (H, W, 64)
+    assert torch.equal(extras["z_vals"].cpu(), torch.from_numpy(g["render_extra_z_vals"]))
+    close(extras["rgb_coarse"], g["render_extra_rgb_coarse"], atol=tol)
+    close(extras["weights"], g["render_extra_weights"], atol=tol)
+
+
+# ------------------------------------------------------------------------------------------------ ABI 3: precision per model
+def test_bf16_and_fp32_models_interleaved_on_two_streams():
+    """No process-wide precision switch: a bf16 and an fp32 model (same weights) are queried and trained alternately on
+    two streams; every result equals the one the same model gives when it runs alone."""
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    mk = lambda p: NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=4, precision=p)
+    g = torch.Generator().manual_seed(0)
+    o = torch.nn.functional.normalize(torch.randn(256, 3, generator=g), dim=-1) * 4.0
+    d = -o / 4.0 + 0.25 * torch.randn(256, 3, generator=g)
+    rays = O.pack_rays(o, d, 2.0, 6.0).to(DEV)
+    z = torch.sort(torch.rand(256, 96, generator=g) * 4 + 2, -1).values.to(DEV)
+    d_raw = torch.randn(256, 96, 4, generator=g).to(DEV)
+    alone = {}
+    for p in (16, 32):
+        m = mk(p)
+        raw = m.query(rays, z, train=True)
+        alone[p] = (raw.clone(), m.backward(d_raw).clone())
+    torch.cuda.synchronize()
+    m16, m32 = mk(16), mk(32)
+    assert m16.packed().numel() < m32.packed().numel()                        # the fp32 image carries the fp32 streams too
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+    got = {16: [], 32: []}
+    for _ in range(3):
+        for m, s, p in ((m16, s1, 16), (m32, s2, 32)):
+            with torch.cuda.stream(s):
+                raw = m.query(rays, z, train=True)
+                got[p].append((raw.clone(), m.backward(d_raw).clone()))
+    torch.cuda.synchronize()
+    for raw, gr in got[16]:
+        assert torch.equal(raw, alone[16][0]) and torch.equal(gr, alone[16][1])           # bf16 path is bit-deterministic
+    for raw, gr in got[32]:
+        assert torch.equal(raw, alone[32][0])
+        assert float((gr - alone[32][1]).norm() / alone[32][1].norm()) < 1e-5             # fp32 dW: float atomics (order)
+    rel = float((alone[16][0] - alone[32][0]).abs().max() / alone[32][0].abs().max())
+    assert 1e-5 < rel < 3e-2                                                               # and they ARE different arithmetics
+
+
+def test_add_noise_z_broadcasts_or_refuses_t_rand():
+    from nerf_meets_mlx_amd import sampling
+    z = torch.sort(torch.rand(9, 16) * 4 + 2, -1).values
+    t_row, t_col = torch.rand(16), torch.rand(9, 1)
+    for t in (t_row, t_col):
+        got = sampling.add_noise_z(z.to(DEV), 1.0, t.to(DEV)).cpu()
+        np.testing.assert_allclose(got.numpy(), O.add_noise_z(z, 1.0, t.expand_as(z)).numpy(), atol=5e-7)
+    with pytest.raises(RuntimeError):
+        sampling.add_noise_z(z.to(DEV), 1.0, torch.rand(9, 5).to(DEV))                    # not broadcastable: refused, no OOB read
+
+
+# ------------------------------------------------------------------------------------------------ a3 as a sampler
+def test_pixel_permutation_device_is_a_uniform_sampler():
+    """Device side of tests/test_host_cpu.py::test_pixel_permutation_is_a_uniform_sampler: 512 keys x the first 1024 of
+    640 000 outputs, chi-square over 64 equal bins of the pixel range, next to numpy's choice(replace=False)."""
+    from nerf_meets_mlx_amd.ops import index
+    dom, n, bins = 640000, 1024, 64
+    cnt = np.zeros(bins)
+    for seed in range(512):
+        v = index.pixel_permutation(n, dom, 1000 + seed, 0, DEV).cpu().numpy()
+        assert len(np.unique(v)) == n and np.array_equal(v, index.pixel_permutation_host(n, dom, 1000 + seed, 0))
+        cnt += np.bincount(v * bins // dom, minlength=bins)
+    e = 512 * n / bins
+    chi2 = float(((cnt - e) ** 2 / e).sum())
+    assert chi2 < 110.0, chi2                                                              # chi2(63): mean 63, 99.98 % quantile ~ 110

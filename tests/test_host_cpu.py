@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in nerf_hip.h but not exported"
         assert s in _native.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_native.SIGNATURES) == set(syms)
-    assert lib.nerf_abi_version() == 2                       # host-only call, no GPU needed
+    assert lib.nerf_abi_version() == 3                       # host-only call, no GPU needed
 
 
 def test_host_argument_validation_without_gpu():
@@ -41,22 +41,26 @@ def test_host_argument_validation_without_gpu():
     assert b"NULL" in lib.nerf_last_error()
     assert lib.nerf_importance_sample(C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 4, 300, 8, 1e-5, None, None, None,
                                       None, None) == -2                      # NERF_E_SHAPE
-    arch = _native.MlpArch(8, 256, 63, 27, 4, 1, 4)
-    assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844
+    arch = _native.MlpArch(8, 256, 63, 27, 4, 1, 4, 16)
+    arch32 = _native.MlpArch(8, 256, 63, 27, 4, 1, 4, 32)               # ABI 3: precision is a field of the arch
+    assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844 == lib.nerf_mlp_param_count(C.byref(arch32))
     bf16_image = (1184 + 1120) * 1024 + 2496 * 4 + 1184 * 1024          # fwd + bwd streams, biases, 16x16x32 stream
     fp32_image = (580 + 544) * 4096 + 3136 * 4                           # fp32 reference-precision streams + tail
-    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == bf16_image + fp32_image
+    assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == bf16_image
+    assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 63, 27, 4, 1, 4, 0))) == bf16_image     # 0 = default = 16
+    assert lib.nerf_mlp_packed_bytes(C.byref(arch32)) == bf16_image + fp32_image
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
-    assert lib.nerf_get_option(b"mlp_precision") == 16 and lib.nerf_get_option(b"nonsense") == -1
-    assert lib.nerf_set_option(b"mlp_precision", 24) == -3                        # NERF_E_UNSUPPORTED
-    assert lib.nerf_set_option(b"mlp_precision", 32) == 0
-    assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 3 * 2528 * 128           # fp32 stores: rows x 32 floats per tile
-    assert lib.nerf_mlp_dz_bytes(C.byref(arch), 65) == 3 * 2496 * 128
-    assert lib.nerf_set_option(b"mlp_precision", 16) == 0
-    img = _native.MlpArch(8, 256, 40, 0, 4, 0, 3)
+    assert lib.nerf_mlp_acts_bytes(C.byref(arch32), 65) == 3 * 2528 * 128         # fp32 stores: rows x 32 floats per tile
+    assert lib.nerf_mlp_dz_bytes(C.byref(arch32), 65) == 3 * 2496 * 128
+    assert lib.nerf_get_option(b"mlp_precision") == -1 and lib.nerf_get_option(b"nonsense") == -1
+    assert lib.nerf_set_option(b"mlp_precision", 32) == -3                        # gone: NERF_E_UNSUPPORTED, with a pointer to the arch
+    assert b"nerf_mlp_arch.precision" in lib.nerf_last_error()
+    img = _native.MlpArch(8, 256, 40, 0, 4, 0, 3, 16)
     assert lib.nerf_mlp_param_count(C.byref(img)) == 482051
-    bad = _native.MlpArch(8, 128, 63, 27, 4, 1, 4)
+    bad = _native.MlpArch(8, 128, 63, 27, 4, 1, 4, 16)
     assert lib.nerf_mlp_param_count(C.byref(bad)) == -1
+    assert lib.nerf_mlp_param_count(C.byref(_native.MlpArch(8, 256, 63, 27, 4, 1, 4, 24))) == -1       # unknown precision
+    assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 40, 0, 4, 0, 3, 32))) == -1        # fp32: view model only
     with pytest.raises(ValueError):
         _native.ptr(torch.zeros(3))                                          # CPU tensors are refused: no fallback
 
@@ -188,3 +192,56 @@ def test_bench_reads_pmc_tables_with_and_without_quotes(tmp_path):
         assert b._read_pmc_busy(str(f), "mlp_dw_kernel") == 0.297
         assert b._read_pmc_busy(str(f), "no_such_kernel") is None
     assert b._read_pmc_busy(str(tmp_path / "absent.csv"), "x") is None
+
+
+def test_counter_seed_streams_are_disjoint_and_stateless():
+    """Trainer randomness is a function of (seed, rank, stream, iteration): no RNG state in checkpoints, and a resumed
+    rank != 0 keeps its own streams (rank 0's saved generators used to overwrite every rank's)."""
+    from nerf_meets_mlx_amd import parallel
+    seen = set()
+    for rank in range(8):
+        for stream in (1, 2, 3):
+            for it in range(0, 2000, 7):
+                s = parallel.counter_seed(4, rank, stream, it)
+                assert 0 <= s < (1 << 63)
+                seen.add(s)
+    assert len(seen) == 8 * 3 * len(range(0, 2000, 7))                                 # no (rank, stream, it) collisions
+    assert parallel.counter_seed(4, 1, 2, 10) == parallel.counter_seed(4, 1, 2, 10)    # stateless
+    assert parallel.counter_seed(4, 0, 2, 7919) != parallel.counter_seed(4, 1, 2, 0)   # the old seed + it scheme collided here
+
+
+def test_pixel_permutation_is_a_uniform_sampler():
+    """The batch of a training iteration is `np.random.choice(H*W, N_rand, replace=False)` upstream
+    (entrypoints/__test_nerf.py:229); here it is the first N_rand outputs of a keyed 4-round Feistel bijection of
+    [0, H*W) (csrc/rays.hip perm_kernel; `pixel_permutation_host` is its bit-exact mirror, compared on the device in
+    tests/test_gpu_parity.py).  Being a bijection is not enough to be a SAMPLER: over 10^4 keys the first 1024 of
+    640 000 outputs must be uniform over the pixel range, over (row, col), in the low bits, with independent consecutive
+    outputs and key-to-key overlap like independent draws -- each statistic next to the same statistic of numpy's choice,
+    with chi-square bounds at mean + 5 sigma."""
+    from nerf_meets_mlx_amd.ops.index import pixel_permutation_host
+    dom, n, S = 640000, 1024, 10000
+    A = np.stack([pixel_permutation_host(n, dom, 1000 + s, 0) for s in range(S)])
+    rng = np.random.default_rng(1)
+    B = np.stack([rng.choice(dom, n, replace=False) for _ in range(S)])
+
+    def chi2(counts):
+        e = counts.sum() / counts.size
+        return float(((counts - e) ** 2 / e).sum())
+
+    def bound(df):
+        return df + 5.0 * np.sqrt(2.0 * df)
+
+    for name, X in (("feistel", A), ("numpy", B)):
+        assert all(len(np.unique(X[i])) == n for i in range(0, S, 500)), name                  # without replacement
+        marg = chi2(np.bincount(X.reshape(-1) * 256 // dom, minlength=256))                     # uniform over the pixel list
+        pairs = chi2(np.bincount(((X[:, :-1] * 16 // dom) * 16 + (X[:, 1:] * 16 // dom)).reshape(-1), minlength=256))   # consecutive outputs independent
+        first = chi2(np.bincount(X[:, 0] * 32 // dom, minlength=32))                            # output 0 across keys
+        rc = chi2(np.bincount((((X // 800) * 8 // 800) * 8 + ((X % 800) * 8 // 800)).reshape(-1), minlength=64))        # (row, col) blocks
+        low = chi2(np.bincount(X.reshape(-1) & 255, minlength=256))                             # low index bits
+        x = X.astype(np.float64) / dom - 0.5
+        corr = float((x[:, :-1] * x[:, 1:]).mean() * 12.0)                                      # lag-1 serial correlation
+        overlap = float(np.mean([len(np.intersect1d(X[i], X[i + 1])) for i in range(2000)]))    # E = 1024^2 / 640000 = 1.64
+        assert marg < bound(255) and pairs < bound(255) and low < bound(255), (name, marg, pairs, low)
+        assert first < bound(31) and rc < bound(63), (name, first, rc)
+        assert abs(corr) < 5.0 / np.sqrt(S * (n - 1)) * 1.2, (name, corr)
+        assert 1.3 < overlap < 2.0, (name, overlap)

@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
-"""Throughput of the fp32 reference-precision mode (nerf_set_option("mlp_precision", 32), csrc/mlp32.hip) against the fp32
+"""Throughput of the fp32 reference-precision mode (NeRF(precision=32) = nerf_mlp_arch.precision 32, csrc/mlp32.hip) against the fp32
 matrix peak (157.3 TFLOP/s, MI355X_MICROARCH.md), next to the bf16 mode on the same inputs.
 
     python tools/probe_fp32.py > profiles/r02_fp32_mode.csv
 """
 import sys, torch
 sys.path.insert(0, ".")
-from nerf_meets_mlx_amd import _native
 from nerf_meets_mlx_amd.models.NeRF import NeRF
 dev = "cuda"
 FLOP = 2 * 593408
@@ -28,10 +27,9 @@ def timeit(fn, it=5):
     return e0.elapsed_time(e1) / it
 
 
-m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0)
 print("mode,pass,rays,samples_per_ray,ms,TFLOP_per_s,frac_of_peak")
 for bits, peak in ((32, 157.3), (16, 2500.0)):
-    _native.check(_native.lib().nerf_set_option(b"mlp_precision", bits))
+    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0, precision=bits)
     for B, n in ((4096, 64), (4096, 192), (32768, 192)):
         r = rays(B); z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
         g = torch.randn(B, n, 4, device=dev)
@@ -42,4 +40,3 @@ for bits, peak in ((32, 157.3), (16, 2500.0)):
                 m.query(r, z, train=True); m.backward(g)
             t = timeit(step)
             print(f"fp{bits},forward+backward (train),{B},{n},{t:.3f},{3 * FLOP * B * n / t / 1e9:.1f},{3 * FLOP * B * n / t / 1e9 / peak:.3f}")
-_native.check(_native.lib().nerf_set_option(b"mlp_precision", 16))

@@ -50,7 +50,7 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
     extra: witnesses trained on the same batches to separate precision from trajectory noise --
       "hip2": a second HIP trainer (same seed; differs from the first only through the order of float atomics),
       "emu":  the oracle with bf16 operand / dZ rounding emulated (same rounding points as the kernels, torch fp32 ops),
-      "hip32": a HIP trainer in the fp32 reference-precision mode (nerf_set_option("mlp_precision", 32) per step).
+      "hip32": a HIP trainer whose networks are fp32 (Trainer(precision=32): the reference's own arithmetic).
     cross: at every checkpoint also compare the two implementations ON THE SAME PARAMETERS (no trajectory involved):
       the oracle renders the HIP trainer's weights and the HIP renderer the oracle's (PSNR differences in dB), and both
       compute the coarse / fine gradient of the current batch at the HIP trainer's weights (cosine, rel-L2).  Training is
@@ -77,16 +77,13 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
                  seed=seed, device=dev, lrate_decay=lrate_decay, ref_quirks=quirks)
     ot = O.OracleTrainer(arch, 64, n_importance, seed=seed, lrate_decay=lrate_decay, ref_quirks=quirks, device=oracle_device)
     assert torch.equal(tr.coarse.params.cpu(), ot.pc.detach().cpu())
-    mk_hip = lambda: Trainer(imgs[:-test_views], poses[:-test_views], K, N_rand=n_rand, n_depth_samples=64,
-                             N_importance=n_importance, seed=seed, device=dev, lrate_decay=lrate_decay, ref_quirks=quirks)
+    mk_hip = lambda precision=16: Trainer(imgs[:-test_views], poses[:-test_views], K, N_rand=n_rand, n_depth_samples=64,
+                                          N_importance=n_importance, seed=seed, device=dev, lrate_decay=lrate_decay,
+                                          ref_quirks=quirks, precision=precision)
     tr2 = mk_hip() if "hip2" in extra else None
-    tr32 = mk_hip() if "hip32" in extra else None
+    tr32 = mk_hip(32) if "hip32" in extra else None
     oe = O.OracleTrainer(arch, 64, n_importance, seed=seed, lrate_decay=lrate_decay, ref_quirks=quirks, device=oracle_device,
                          emulate_bf16=True) if "emu" in extra else None
-    from nerf_meets_mlx_amd import _native
-
-    def precision(bits):
-        _native.check(_native.lib().nerf_set_option(b"mlp_precision", bits))
     g = torch.Generator().manual_seed(123)
     od = torch.device(oracle_device)
     NI = max(n_importance, 1)
@@ -196,9 +193,7 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
         if tr2 is not None:
             tr2.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
         if tr32 is not None:
-            precision(32)
             tr32.train_step(rays, target, u.to(dev) if n_importance > 0 else None)
-            precision(16)
         if oe is not None:
             oe.step(rays[:, 0:3].to(od), rays[:, 3:6].to(od), target.to(od), u.to(od))
         if it % every == 0 or it == iters:
@@ -211,9 +206,7 @@ def run(hw=64, n_rand=256, iters=300, every=100, views=12, test_views=2, n_impor
             if tr2 is not None:
                 rec["psnr_hip2"] = hip_psnr(tr2)
             if tr32 is not None:
-                precision(32)
                 rec["psnr_hip32"] = hip_psnr(tr32)
-                precision(16)
             if oe is not None:
                 rec["psnr_oracle_emu_bf16"] = oracle_psnr(oe)
             if n_importance > 0:
