@@ -146,6 +146,14 @@ int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, in
                                 int log2_T, int F, const int* resolutions_host, float pos_scale, float pos_offset,
                                 float* d_tables, void* stream);
 
+/* The same for levels [level_lo, level_hi) only (the launches of disjoint level groups can be followed one by one by the
+ * all-reduce of their slice of d_tables on another stream), and optionally DETERMINISTIC: fixed_point = 1 makes d_tables
+ * an int64 [L,T,F] array of 2^-52 fixed-point accumulators added with integer atomics (associative: the result does not
+ * depend on the order the memory side serves the requests; float atomics do).  nerf_adam_step_ex consumes either form.  */
+int nerf_hashgrid_backward_rays_ex(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,
+                                   int log2_T, int F, const int* resolutions_host, float pos_scale, float pos_offset,
+                                   int level_lo, int level_hi, int fixed_point, void* d_tables, void* stream);
+
 /* ---------------------------------------------------------------- compositing (a13)
  * replaces: rendering/render.py:20-96 raw2outputs.  raw [B,n,4] = [rgb, sigma];
  * noise [B,n] (N(0,1), caller's RNG) may be NULL when raw_noise_std == 0.
@@ -320,6 +328,12 @@ int nerf_get_option(const char* key);
  * grad_scale first (1/world_size after a sum all-reduce).                               */
 int nerf_adam_step(float* params, const float* grads, float* m, float* v, int64_t count, float lr, float beta1,
                    float beta2, float eps, int bias_correction, int step, float grad_scale, void* stream);
+/* Same update; grads is float32 [count] (grads_fixed_point = 0) or the int64 [count] fixed-point accumulators of
+ * nerf_hashgrid_backward_rays_ex (1), and with zero_grads != 0 the gradient buffer is cleared in the same pass (read g,
+ * write 0) so that an accumulating scatter needs no memset before the next step.                                  */
+int nerf_adam_step_ex(float* params, void* grads, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                      float eps, int bias_correction, int step, float grad_scale, int grads_fixed_point, int zero_grads,
+                      void* stream);
 
 #ifdef __cplusplus
 }

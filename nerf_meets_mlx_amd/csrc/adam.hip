@@ -1,6 +1,7 @@
 // Fused multi-tensor Adam over one flat float32 parameter buffer (a21 / K9).
 // HBM-bound: 28 B per parameter (read p,g,m,v; write p,m,v) = 16.7 MB per network.
 #include "common.h"
+#include "hash_common.h"
 
 namespace nerf {
 
@@ -19,9 +20,49 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// The same update with (a) the gradient taken from float32 values OR from the int64 fixed-point accumulators of the
+// deterministic hash-grid scatter (hash_common.h: 2^-52 units), and (b) the gradient buffer zeroed in the same pass
+// (read g, write 0): the next step's scatter needs no memset launch.
+template <bool FIXED, bool ZERO>
+__global__ void __launch_bounds__(256) adam_ex_kernel(float* __restrict__ p, void* __restrict__ gv, float* __restrict__ m,
+                                                      float* __restrict__ v, int64_t count, float lr, float b1, float b2,
+                                                      float eps, float c1, float c2, float gscale) {
+  float* gf = static_cast<float*>(gv);
+  long long* gi64 = static_cast<long long*>(gv);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi;
+    if (FIXED) { gi = (float)((double)gi64[i] * (1.0 / NERF_HASH_FIX_SCALE)) * gscale; if (ZERO) gi64[i] = 0; }
+    else { gi = gf[i] * gscale; if (ZERO) gf[i] = 0.0f; }
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+  }
+}
+
 }  // namespace nerf
 
 using namespace nerf;
+
+extern "C" int nerf_adam_step_ex(float* params, void* grads, float* m, float* v, int64_t count, float lr, float beta1,
+                                 float beta2, float eps, int bias_correction, int step, float grad_scale, int grads_fixed_point,
+                                 int zero_grads, void* stream) {
+  NERF_REQUIRE(params && grads && m && v, NERF_E_NULL, "nerf_adam_step_ex: NULL pointer");
+  NERF_REQUIRE(count > 0, NERF_E_SHAPE, "nerf_adam_step_ex: count must be > 0");
+  float c1 = 1.0f, c2 = 1.0f;
+  if (bias_correction) {
+    NERF_REQUIRE(step >= 1, NERF_E_SHAPE, "nerf_adam_step_ex: bias correction needs step >= 1");
+    c1 = 1.0f / (1.0f - powf(beta1, (float)step));
+    c2 = 1.0f / (1.0f - powf(beta2, (float)step));
+  }
+  const dim3 g(grid_for(count, 256)), b(256);
+  auto s = as_stream(stream);
+#define AX(FX, ZR) hipLaunchKernelGGL((adam_ex_kernel<FX, ZR>), g, b, 0, s, params, grads, m, v, count, lr, beta1, beta2, eps, c1, c2, grad_scale)
+  if (grads_fixed_point) { if (zero_grads) AX(true, true); else AX(true, false); }
+  else { if (zero_grads) AX(false, true); else AX(false, false); }
+#undef AX
+  return check_launch("nerf_adam_step_ex");
+}
 
 extern "C" int nerf_adam_step(float* params, const float* grads, float* m, float* v, int64_t count, float lr,
                               float beta1, float beta2, float eps, int bias_correction, int step, float grad_scale,

@@ -112,13 +112,24 @@ __global__ void __launch_bounds__(256) ngp_dir_rows_kernel(const float* __restri
 // two x-neighbours differ only in the low bits of the index (same 128-byte line unless a carry crosses bit 3 for
 // F = 2: 15 of 16 cases), so one instruction touches ~16 lines for 64 lanes where the per-(sample, feature) mapping
 // touched 32 and the per-sample mapping 64.  Each lane issues the 4 (y, z) corner combinations of its x plane.
-template <int F, int LG>
+// FIXED (deterministic mode): every addend is converted to a 64-bit fixed-point number (2^-NERF_HASH_FIX_SHIFT units) and
+// added with an INTEGER atomic: integer addition is associative, so the accumulated table gradient does not depend on
+// the order in which the memory side serves the requests -- bit-reproducible run to run, unlike float atomics -- and it
+// is also the exactly rounded sum of the quantised addends (|addend| < 2^11, resolution 2^-52: finer than float32 for
+// every addend above 3e-9, and Adam's eps = 1e-8 hides what is below).  nerf_adam_step_ex reads the accumulators.
+template <int F, int LG, bool FIXED>
 __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t M,
-                                                           float* __restrict__ d_tables, const float* __restrict__ d_out,
-                                                           int L, uint32_t T, ResTab rt) {
-  const int l0 = blockIdx.y * LG;
+                                                           void* __restrict__ d_tables_v, const float* __restrict__ d_out,
+                                                           int L, uint32_t T, ResTab rt, int level_lo, int level_hi) {
+  const int l0 = level_lo + blockIdx.y * LG;
   const uint32_t mask = T - 1;
   const int64_t total = M * (2 * F);
+  float* d_tables = static_cast<float*>(d_tables_v);
+  unsigned long long* d_fixed = static_cast<unsigned long long*>(d_tables_v);
+  auto add = [&](size_t idx, float v) {
+    if (FIXED) atomicAdd(d_fixed + idx, (unsigned long long)(long long)__double2ll_rn((double)v * NERF_HASH_FIX_SCALE));
+    else atomicAdd(d_tables + idx, v);
+  };
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = t / (2 * F);
     const int q = (int)(t - m * (2 * F)), f = q % F, dx = q / F;
@@ -127,7 +138,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t 
 #pragma unroll
     for (int li = 0; li < LG; ++li) {
       const int l = l0 + li;
-      if (l >= L) break;
+      if (l >= level_hi) break;
       const float r = rt.res[l];
       // same roundings as corners_of (hash_common.h): xs = p * r, floor / ceil, offset = xs - floor
       const float xs = px * r, ys = py * r, zs = pz * r;
@@ -136,14 +147,14 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t 
       const uint32_t cx = (uint32_t)(int32_t)(dx ? ceilf(xs) : fx);
       const uint32_t yf = (uint32_t)(int32_t)fy * 2654435761u, yc = (uint32_t)(int32_t)ceilf(ys) * 2654435761u;
       const uint32_t zf = (uint32_t)(int32_t)fz * 805459861u, zc = (uint32_t)(int32_t)ceilf(zs) * 805459861u;
-      float* tb = d_tables + (size_t)l * T * F + f;
+      const size_t tb = (size_t)l * T * F + f;
       const float g = d_out[(m * L + l) * F + f];
       // products in the order of the per-corner form (g * wz * wy * wx), so every addend is bit-identical to it
       const float wx = dx ? ox : 1 - ox;
-      atomicAdd(tb + (size_t)((cx ^ yc ^ zc) & mask) * F, g * oz * oy * wx);
-      atomicAdd(tb + (size_t)((cx ^ yf ^ zc) & mask) * F, g * oz * (1 - oy) * wx);
-      atomicAdd(tb + (size_t)((cx ^ yc ^ zf) & mask) * F, g * (1 - oz) * oy * wx);
-      atomicAdd(tb + (size_t)((cx ^ yf ^ zf) & mask) * F, g * (1 - oz) * (1 - oy) * wx);
+      add(tb + (size_t)((cx ^ yc ^ zc) & mask) * F, g * oz * oy * wx);
+      add(tb + (size_t)((cx ^ yf ^ zc) & mask) * F, g * oz * (1 - oy) * wx);
+      add(tb + (size_t)((cx ^ yc ^ zf) & mask) * F, g * (1 - oz) * oy * wx);
+      add(tb + (size_t)((cx ^ yf ^ zf) & mask) * F, g * (1 - oz) * (1 - oy) * wx);
     }
   }
 }
@@ -152,7 +163,8 @@ template <bool BWD>
 static int launch_hashgrid(const float* x, int64_t M, const float* tables, float* d_tables, const float* d_out, int L,
                            int log2_T, int F, const int* res, float* out, void* stream, const char* who,
                            const float* rays = nullptr, const float* z = nullptr, int n = 1, int64_t out_stride = 0,
-                           float pos_scale = 1.0f, float pos_offset = 0.0f) {
+                           float pos_scale = 1.0f, float pos_offset = 0.0f, int level_lo = 0, int level_hi = -1,
+                           bool fixed = false) {
   NERF_REQUIRE((x || (rays && z)) && res, NERF_E_NULL, "%s: NULL pointer", who);
   NERF_REQUIRE(L >= 1 && L <= 32 && log2_T >= 1 && log2_T <= 30, NERF_E_SHAPE, "%s: need 1<=L<=32, 1<=log2_T<=30", who);
   NERF_REQUIRE(F == 1 || F == 2 || F == 4 || F == 8, NERF_E_UNSUPPORTED, "%s: F must be 1, 2, 4 or 8", who);
@@ -161,9 +173,14 @@ static int launch_hashgrid(const float* x, int64_t M, const float* tables, float
   for (int l = 0; l < L; ++l) rt.res[l] = (float)res[l];
   const uint32_t T = 1u << log2_T;
   constexpr int LG = 4;                                   // levels per thread: LG x F contiguous floats per sample
-  const dim3 g(grid_for(BWD ? M * F * 2 : M, 256, 256 * 32), (unsigned)((L + LG - 1) / LG)), b(256);
+  if (level_hi < 0) level_hi = L;
+  NERF_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= L, NERF_E_SHAPE, "%s: need 0 <= level_lo <= level_hi <= L", who);
+  if (level_lo == level_hi) return NERF_OK;
+  const int nlev = BWD ? level_hi - level_lo : L;
+  const dim3 g(grid_for(BWD ? M * F * 2 : M, 256, 256 * 32), (unsigned)((nlev + LG - 1) / LG)), b(256);
   auto st = as_stream(stream);
-#define HG(FF) do { if (BWD) hipLaunchKernelGGL((hashgrid_bwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, d_tables, d_out, L, T, rt); \
+#define HG(FF) do { if (BWD && fixed) hipLaunchKernelGGL((hashgrid_bwd_kernel<FF, LG, true>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, (void*)d_tables, d_out, L, T, rt, level_lo, level_hi); \
+                    else if (BWD) hipLaunchKernelGGL((hashgrid_bwd_kernel<FF, LG, false>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, (void*)d_tables, d_out, L, T, rt, level_lo, level_hi); \
                     else hipLaunchKernelGGL((hashgrid_fwd_kernel<FF, LG>), g, b, 0, st, PointSrc{x, rays, z, n, pos_scale, pos_offset}, M, tables, L, T, rt, out, \
                                             out_stride > 0 ? out_stride : (int64_t)L * FF); } while (0)
   switch (F) { case 1: HG(1); break; case 2: HG(2); break; case 4: HG(4); break; default: HG(8); }
@@ -237,6 +254,18 @@ extern "C" int nerf_ngp_encode(const float* rays, const float* z, int64_t B, int
   hipLaunchKernelGGL(ngp_dir_rows_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), rays, z, n, M, sh_degree,
                      x_out, stride, L * F, pts_out, pos_scale, pos_offset);
   return check_launch("nerf_ngp_encode");
+}
+
+extern "C" int nerf_hashgrid_backward_rays_ex(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,
+                                              int log2_T, int F, const int* resolutions_host, float pos_scale,
+                                              float pos_offset, int level_lo, int level_hi, int fixed_point,
+                                              void* d_tables, void* stream) {
+  if (B <= 0 || n <= 0) return NERF_OK;
+  NERF_REQUIRE(rays && z && d_out && d_tables, NERF_E_NULL, "nerf_hashgrid_backward_rays_ex: NULL pointer");
+  NERF_REQUIRE(fixed_point == 0 || fixed_point == 1, NERF_E_UNSUPPORTED, "nerf_hashgrid_backward_rays_ex: fixed_point must be 0 or 1");
+  return launch_hashgrid<true>(nullptr, B * n, nullptr, static_cast<float*>(d_tables), d_out, L, log2_T, F, resolutions_host,
+                               nullptr, stream, "nerf_hashgrid_backward_rays_ex", rays, z, n, 0, pos_scale, pos_offset,
+                               level_lo, level_hi, fixed_point != 0);
 }
 
 extern "C" int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,

@@ -32,6 +32,10 @@ __device__ __forceinline__ void sh_eval(float x, float y, float z, int deg, floa
 }
 struct ResTab { float res[32]; };
 
+// fixed-point unit of the deterministic table-gradient accumulators (int64): 2^-52
+#define NERF_HASH_FIX_SHIFT 52
+#define NERF_HASH_FIX_SCALE 4503599627370496.0
+
 __device__ __forceinline__ uint32_t hash3(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t mask) {
   return ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) & mask;     // uint32 wrap-around, mod T = & (T-1)
 }

@@ -9,8 +9,11 @@ trained by the coarse-only loop of `render_rays` (rendering/render.py:112-162) +
 
 Device work: nerf_hashgrid_forward / nerf_sh_encode -> nerf_mlp_forward_train (2 x 64 kernels) ->
 nerf_composite_mse_backward (raw2outputs + MSE + adjoint, one launch) -> nerf_mlp_backward_inputs (dZ chain, dW,
-dL/dfeatures) -> nerf_hashgrid_backward (float atomics) -> nerf_adam_step x 2.  torch only concatenates the two
-feature blocks and forms o + z d.
+dL/dfeatures) -> nerf_hashgrid_backward_rays_ex per LEVEL GROUP (float atomics, or -- `deterministic=True` -- int64
+fixed-point integer atomics whose sum does not depend on the order of the requests) -> nerf_adam_step (MLP) and
+nerf_adam_step_ex (tables: reads the accumulated gradient and clears it in the same pass, no memset launch).
+With world_size > 1 the table gradient (64 MB float32 / 128 MB int64) is all-reduced group by group on a second
+stream while the next group's scatter, the MLP all-reduce and the MLP Adam run (NGPTrainer.train_step).
 """
 import ctypes as C
 import os
@@ -31,7 +34,7 @@ class _Flat:
     """Adam-compatible view of a flat trainable buffer (the hash tables)."""
 
     def __init__(self, params: torch.Tensor, grads: torch.Tensor):
-        self.params, self.grads, self.n_params = params.view(-1), grads.view(-1), params.numel()
+        self.params, self.grads, self.n_params = params.view(-1), grads.view(-1), params.numel()     # grads: float32 or int64 fixed point
         self.name = "tables"
 
     def mark_updated(self):
@@ -48,7 +51,7 @@ class HashNeRF:
 
     def __init__(self, device="cuda", seed: int = 0, n_levels: int = 16, min_res: int = 16, max_res: int = 2048,
                  n_features_per_level: int = 2, log2_hashmap_size: int = 19, hash_init_scale: float = 1e-4,
-                 bound: Optional[float] = 1.5):
+                 bound: Optional[float] = 1.5, deterministic: bool = False, level_groups: int = 4):
         """bound: half-extent of the scene box that is mapped onto the grid's unit cube before hashing
         (x' = (x + bound) / (2 bound)), so that N_l is the level's resolution ACROSS the scene (without it the reference's
         x * N_l sees world units: 3 x finer cells, and a 24-view run memorises its training rays: held-out PSNR 13.8 dB
@@ -60,7 +63,15 @@ class HashNeRF:
         self.mlp = NeRF(n_layers=2, width_layers=64, channel_input=32, channel_input_views=16,
                         list_skip_connection_layers=[], is_use_view_directions=True, device=device, seed=seed)
         self.pos_scale, self.pos_offset = (1.0, 0.0) if bound is None else (1.0 / (2.0 * bound), 0.5)
+        # table-gradient accumulator: float32 (float atomics: fast, order-dependent rounding) or int64 2^-52 fixed point
+        # (integer atomics: bit-reproducible).  It is cleared by the Adam pass that consumes it, never by a memset.
+        self.deterministic = bool(deterministic)
+        if self.deterministic:
+            self.enc.grad = torch.zeros(self.enc.tables.shape, dtype=torch.int64, device=self.enc.tables.device)
         self.table = _Flat(self.enc.tables, self.enc.grad)
+        ng = max(1, min(int(level_groups), n_levels))
+        self.level_groups = [(n_levels * i // ng, n_levels * (i + 1) // ng) for i in range(ng)]
+        self.on_group_done = None           # NGPTrainer: called after each level group's scatter is enqueued (lo, hi)
         self._pts, self._rz = None, None
         self.fused = os.environ.get("NERF_NGP_FUSED", "1") != "0"      # rows inside the forward kernel (default) or through HBM
         self.timing = None                  # bench.py: list that receives (start, end) events around the table scatter
@@ -114,17 +125,24 @@ class HashNeRF:
         """(MLP gradient [13188], table gradient [L,T,F]) of the last query(train=True)."""
         grads, d_x = self.mlp.backward(d_raw, need_input_grad=True)
         e = self.enc
-        e.grad.zero_()
         if self.timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self._rz is not None:
-            rays, z = self._rz
-            N.check(N.lib().nerf_hashgrid_backward_rays(N.ptr(rays), N.ptr(z), z.shape[0], z.shape[1], N.ptr(d_x), e.n_levels,
-                                                        e.log2_hashmap_size, e.n_features_per_level, e._res_c,
-                                                        self.pos_scale, self.pos_offset, N.ptr(e.grad), N.stream()))
-        else:
+        if self._rz is None:                                 # unfused rows: positions were kept by features()
+            if self.deterministic:
+                raise ValueError("HashNeRF(deterministic=True) needs the fused query (positions from rays / depths)")
             e.backward(self._pts, d_x)
+            if self.on_group_done is not None:
+                self.on_group_done(0, e.n_levels)
+        else:
+            rays, z = self._rz
+            for lo, hi in self.level_groups:
+                N.check(N.lib().nerf_hashgrid_backward_rays_ex(
+                    N.ptr(rays), N.ptr(z), z.shape[0], z.shape[1], N.ptr(d_x), e.n_levels, e.log2_hashmap_size,
+                    e.n_features_per_level, e._res_c, self.pos_scale, self.pos_offset, lo, hi, int(self.deterministic),
+                    N.ptr(e.grad), N.stream()))
+                if self.on_group_done is not None:
+                    self.on_group_done(lo, hi)
         if self.timing is not None:
             e1.record()
             self.timing.append((e0, e1))
@@ -149,6 +167,7 @@ class NGPTrainer(Trainer):
         # reference's un-activated sigma).  This loop is our wiring, so the choice is ours; lrate is
         # the reference's 5e-4 (at 2e-3 both this trainer and the fp32 oracle collapse to sigma < 0 within 200 iterations).
         self.opt = Adam(lrate, betas=(0.9, 0.99), eps=1e-8, bias_correction=True, shared_state=False)
+        self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
 
     def train_step(self, rays=None, target=None, u=None) -> Dict[str, torch.Tensor]:
         if rays is None:
@@ -157,11 +176,29 @@ class NGPTrainer(Trainer):
         z = sampling.sample_coarse(rays, self.n)
         raw = self.field.query(rays, z, train=True)
         loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, self.white_bkgd)
+        pending = []
+        if self.world > 1:
+            # all-reduce each level group's slice of the table gradient on the comm stream as soon as its scatter is
+            # enqueued: the transfer overlaps the next group's scatter, the MLP all-reduce and the MLP Adam
+            per_level = self.field.enc.hash_table_size * self.field.enc.n_features_per_level
+            flat = self.field.table.grads
+
+            def group_done(lo, hi):
+                ev = torch.cuda.Event()
+                ev.record()
+                self._comm.wait_event(ev)
+                with torch.cuda.stream(self._comm):
+                    pending.append(torch.distributed.all_reduce(flat[lo * per_level:hi * per_level], async_op=True))
+            self.field.on_group_done = group_done
         g_mlp, g_tab = self.field.backward(d_raw)
+        self.field.on_group_done = None
         parallel.allreduce_sum_(g_mlp)
-        parallel.allreduce_sum_(g_tab.view(-1))
         self.opt.update(self.field.mlp, g_mlp, grad_scale=1.0 / self.world)
-        self.opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world)
+        for w in pending:
+            w.wait()
+        if pending:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        self.opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world, zero_grads=True)    # reads g, writes 0
         self.it += 1
         return {"loss_coarse": loss}
 

@@ -167,9 +167,9 @@ class Trainer:
         if "state" not in adam:                                              # round-1 layout: {key: [m, v]}
             adam = {"state": adam, "step_count": {}}
         self.opt.load_state_dict(adam, device=self.device)
-        if "seed" in sd and int(sd["seed"]) != int(self.seed):
-            raise ValueError(f"checkpoint was written by a run with seed {int(sd['seed'])}, this trainer has seed {self.seed}: "
-                             "its random streams would not continue the saved run")
+        if "seed" in sd:
+            self.seed = int(sd["seed"])      # the streams are functions of (seed, rank, it): adopt the saved run's seed so that
+                                             # this trainer CONTINUES it, whatever seed its own (now overwritten) init used
 
     @staticmethod
     def _npz_path(path: str) -> str:

@@ -229,17 +229,26 @@ class Adam:
             return str(name)
         return self._auto_names.setdefault(id(model), f"model{len(self._auto_names)}")
 
-    def update(self, model: NeRF, grads: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
+    def update(self, model: NeRF, grads: Optional[torch.Tensor] = None, grad_scale: float = 1.0, zero_grads: bool = False):
+        """zero_grads: clear the gradient buffer in the same pass (`nerf_adam_step_ex`: read g, write 0) -- for gradients
+        that are ACCUMULATED by a scatter (the hash tables); an int64 `grads` tensor is taken as the fixed-point accumulators
+        of the deterministic scatter (nerf_hashgrid_backward_rays_ex)."""
         g = model.grads if grads is None else grads
         key = self.key_of(model)
         if key not in self.state:
             self.state[key] = [torch.zeros_like(model.params), torch.zeros_like(model.params)]
         self.step_count[key] = self.step_count.get(key, 0) + 1
         m, v = self.state[key]
-        N.check(N.lib().nerf_adam_step(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
-                                       float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
-                                       float(self.eps), int(self.bias_correction), self.step_count[key],
-                                       float(grad_scale), N.stream()))
+        if zero_grads or g.dtype == torch.int64:
+            N.check(N.lib().nerf_adam_step_ex(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
+                                              float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
+                                              float(self.eps), int(self.bias_correction), self.step_count[key],
+                                              float(grad_scale), int(g.dtype == torch.int64), int(bool(zero_grads)), N.stream()))
+        else:
+            N.check(N.lib().nerf_adam_step(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
+                                           float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
+                                           float(self.eps), int(self.bias_correction), self.step_count[key],
+                                           float(grad_scale), N.stream()))
         model.mark_updated()
 
     def state_dict(self) -> Dict[str, object]:

@@ -529,7 +529,9 @@ def test_trainer_matches_oracle_trainer():
     sd = tr.state_dict()
     tr2 = Trainer(imgs, poses, _lego_K(H, W), N_rand=48, seed=99, device=DEV)
     tr2.load_state_dict(sd)
-    assert torch.equal(tr2.coarse.params, tr.coarse.params) and tr2.it == 4
+    assert torch.equal(tr2.coarse.params, tr.coarse.params) and tr2.it == 4 and tr2.seed == 11      # continues the saved run's streams
+    ra, _ = tr.sample_batch(); rb, _ = tr2.sample_batch()
+    assert torch.equal(ra, rb)
     img = tr.render_frame(poses[0])
     assert img.shape == (H, W, 3) and torch.isfinite(img).all()
 

@@ -196,10 +196,12 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
     return recs, {k: v.summary(iters) for k, v in dead.items()}
 
 
-def summarise(all_recs, key_a="psnr_bf16", key_b="psnr_fp32", label="bf16_minus_fp32"):
+def summarise(all_recs, key_a="psnr_bf16", key_b="psnr_fp32", label="bf16_minus_fp32", only_seeds=None):
+    """Paired statistics per checkpoint.  only_seeds: restrict to these seeds (e.g. those whose networks are alive at the
+    end in BOTH arms: a seed that is dead in both contributes an exact 0 and would pull the mean towards 0)."""
     table = {}
     for r in all_recs:
-        if key_a in r and key_b in r:
+        if key_a in r and key_b in r and (only_seeds is None or r["seed"] in only_seeds):
             table.setdefault(r["iter"], []).append((r["seed"], r[key_a], r[key_b]))
     out = []
     for it, rows in sorted(table.items()):
@@ -219,6 +221,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=32)
     ap.add_argument("--seed-start", type=int, default=0)
+    ap.add_argument("--seed-list", default="", help="explicit comma list of seeds (skips the alive-seed scan): lets one ensemble be split over several calls")
     ap.add_argument("--iters", type=int, default=2500)
     ap.add_argument("--every", type=int, default=250)
     ap.add_argument("--hw", type=int, default=100)
@@ -240,7 +243,7 @@ def main():
         print(line, flush=True)
         if fp:
             fp.write(line + "\n"); fp.flush()
-    seeds = alive_seeds(a.seeds, not a.no_quirks, a.seed_start)
+    seeds = [int(x) for x in a.seed_list.split(",") if x] if a.seed_list else alive_seeds(a.seeds, not a.no_quirks, a.seed_start)
     emit(json.dumps({"config": vars(a), "seeds": seeds, "arms": {"bf16": "Trainer(precision=16)", "fp32": "Trainer(precision=32)"}}))
     if a.bridge > 0:
         brecs = []
@@ -258,6 +261,10 @@ def main():
             recs += r
             deads[sd] = dsum
         for st in summarise(recs):
+            emit(json.dumps(st))
+        dead_any = lambda d: any(d[arm][net]["dead_at_end"] for arm in ("bf16", "fp32") for net in ("coarse", "fine"))
+        alive = {sd for sd, d in deads.items() if not dead_any(d)}
+        for st in summarise(recs, label="bf16_minus_fp32_alive_at_end_in_both_arms", only_seeds=alive):
             emit(json.dumps(st))
         emit(json.dumps({"dead_sigma_summary": {
             arm: {"seeds_ever_dead_fine": [s for s, d in deads.items() if d[arm]["fine"]["dead_iterations"] > 0],
