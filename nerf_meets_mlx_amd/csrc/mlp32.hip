@@ -387,8 +387,13 @@ __global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
   while (unit >= a.unit0[j + 1]) ++j;
   const DwJob32 jb = a.jobs[j];
   const int local = unit - a.unit0[j];
-  const int split = local % a.splits, block = local / a.splits;
+  // block-fastest order: the four waves of a workgroup (and the neighbouring workgroups) work on DIFFERENT 64 x 64 blocks
+  // of the SAME sample slice at the same time, so the dZ / H rows they share (a 256 x 256 job reads every operand row
+  // block 4 times) come from L1 / L2 / Infinity Cache instead of from HBM four times at four different moments
+  // (split-fastest order: 80 KB of reads per sample against 20 KB stored)
   const int kb = (jb.k_tiles + 1) / 2;
+  const int nblocks = ((jb.n_tiles + 1) / 2) * kb;
+  const int block = local % nblocks, split = local / nblocks;
   const int nt0 = 2 * (block / kb), kt0 = 2 * (block % kb);
   const int t_lo = (int)((int64_t)a.ntiles * split / a.splits), t_hi = (int)((int64_t)a.ntiles * (split + 1) / a.splits);
   f32x16 acc[2][2];

@@ -121,10 +121,14 @@ class HashNeRF:
                                              N.stream()))
         return raw
 
-    def backward(self, d_raw: torch.Tensor):
-        """(MLP gradient [13188], table gradient [L,T,F]) of the last query(train=True)."""
+    def backward(self, d_raw: torch.Tensor, accumulate: bool = False):
+        """(MLP gradient [13188], table gradient [L,T,F]: float32, or int64 2^-52 fixed point when deterministic) of the
+        last query(train=True).  accumulate=True adds into the gradient buffer as it stands (NGPTrainer: the Adam pass that
+        consumed the previous gradient left it zeroed); the default clears it first."""
         grads, d_x = self.mlp.backward(d_raw, need_input_grad=True)
         e = self.enc
+        if not accumulate:
+            e.grad.zero_()
         if self.timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -190,7 +194,7 @@ class NGPTrainer(Trainer):
                 with torch.cuda.stream(self._comm):
                     pending.append(torch.distributed.all_reduce(flat[lo * per_level:hi * per_level], async_op=True))
             self.field.on_group_done = group_done
-        g_mlp, g_tab = self.field.backward(d_raw)
+        g_mlp, g_tab = self.field.backward(d_raw, accumulate=True)       # zeroed by the previous step's table Adam
         self.field.on_group_done = None
         parallel.allreduce_sum_(g_mlp)
         self.opt.update(self.field.mlp, g_mlp, grad_scale=1.0 / self.world)

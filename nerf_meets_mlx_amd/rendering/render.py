@@ -70,10 +70,11 @@ def render_rays_fused(rays, network_coarse, network_fine, n_depth_samples, N_imp
     if Nn > 0 and u is None:
         u = torch.rand(B, Nn, dtype=torch.float32, device=dev)
     nbytes = N.lib().nerf_render_workspace_bytes(B, n, Nn)
-    ws = _WS.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)      # one scratch buffer per (device, stream): two streams that
+    ws = _WS.get(key)                                            # render concurrently must not share intermediate z / raw
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _WS[dev] = ws
+        _WS[key] = ws
     f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
     rgb, disp, acc = f(B, 3), f(B), f(B)
     ret = {}

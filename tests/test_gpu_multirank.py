@@ -86,3 +86,51 @@ def test_two_ranks_keep_identical_weights(tmp_path):
     for rank, ok, differ, frame_ok, loss in res:
         assert ok and differ and frame_ok, (rank, ok, differ, frame_ok)
         assert loss == loss
+
+
+def _ngp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from nerf_meets_mlx_amd import parallel
+    from nerf_meets_mlx_amd.dataset import synthetic
+    from nerf_meets_mlx_amd.engine.ngp import NGPTrainer
+    torch.cuda.set_device(0)
+    parallel.init_from_env(backend="gloo")
+    imgs, poses, _, _, K = synthetic.make_dataset(16, 16, 3, seed=0, device="cuda")
+    res = []
+    for det in (True, False):
+        tr = NGPTrainer(imgs, poses, K, N_rand=64, n_depth_samples=64, seed=7, device="cuda", log2_hashmap_size=12,
+                        deterministic=det, level_groups=4)
+        t0 = tr.field.enc.tables.clone()
+        for _ in range(3):
+            out = tr.train_step()
+        torch.cuda.synchronize()
+        ts = [torch.zeros_like(tr.field.enc.tables) for _ in range(world)]
+        dist.all_gather(ts, tr.field.enc.tables)
+        ms = [torch.zeros_like(tr.field.mlp.params) for _ in range(world)]
+        dist.all_gather(ms, tr.field.mlp.params)
+        same = all(torch.equal(ts[0], t) for t in ts) and all(torch.equal(ms[0], m) for m in ms)
+        moved = not torch.equal(t0, tr.field.enc.tables)
+        cleared = float(tr.field.enc.grad.abs().max()) == 0.0
+        res.append((det, same, moved, cleared, float(out["loss_coarse"])))
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_ngp_two_ranks_grouped_table_allreduce_keeps_tables_identical():
+    """configs[4] with world_size 2: the table gradient (float32, or int64 fixed point in deterministic mode) is
+    all-reduced level group by level group on the comm stream while the next group's scatter and the MLP step run; after
+    every step both ranks hold bit-identical tables and MLP weights, and the accumulators are cleared by the Adam pass."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ngp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=280) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        for det, same, moved, cleared, loss in res:
+            assert same and moved and cleared and loss == loss, (rank, det, same, moved, cleared, loss)
