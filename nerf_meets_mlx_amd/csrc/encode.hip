@@ -3,6 +3,7 @@
 // reference's `Encoding` classes and for parity tests, and are HBM/L2-gather bound.
 #include "common.h"
 #include "hash_common.h"
+#include <type_traits>
 
 namespace nerf {
 
@@ -159,6 +160,80 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t 
   }
 }
 
+// Coarse levels: write-combining in LDS.  A workgroup iteration covers 64 consecutive samples (one ray at n = 64); at a
+// coarse level they fall into a handful of cells (3 samples per cell at resolution 16, ~1 at 58), so their 64 x 8 x F
+// addends hit few distinct table entries, and every workgroup of the launch hammers the same few thousand entries of
+// that level (measured: level 0 runs at 28 G atomics/s against 70 G for the fine levels).  Here the addends are first
+// accumulated in a small open-addressing table in LDS (keys: entry index; LDS atomics), then each distinct (entry,
+// feature) is added to the global table ONCE.  In FIXED mode the LDS accumulators are the same int64 fixed-point numbers
+// as the global ones: integer addition is associative, so the result is bit-identical to the direct kernel's.
+int g_hash_combine_max_res = 64;    // A/B knob (nerf_set_option "hash_combine_max_res"): levels with N_l <= this go through LDS; 0 = off
+constexpr int HC_CAP = 1024;                       // slots; at most 64 samples x 8 corners = 512 distinct keys per iteration
+constexpr uint32_t HC_EMPTY = 0xFFFFFFFFu;
+template <int F, bool FIXED>
+__global__ void __launch_bounds__(256) hashgrid_bwd_combine_kernel(PointSrc ps, int64_t M, void* __restrict__ d_tables_v,
+                                                                   const float* __restrict__ d_out, int L, uint32_t T,
+                                                                   ResTab rt, int level_lo) {
+  typedef typename std::conditional<FIXED, unsigned long long, float>::type AccT;
+  __shared__ uint32_t keys[HC_CAP];
+  __shared__ AccT vals[HC_CAP * F];
+  const int l = level_lo + blockIdx.y;
+  const uint32_t mask = T - 1;
+  const float r = rt.res[l];
+  float* d_tables = static_cast<float*>(d_tables_v);
+  unsigned long long* d_fixed = static_cast<unsigned long long*>(d_tables_v);
+  const size_t tb = (size_t)l * T * F;
+  const int tid = threadIdx.x;
+  constexpr int SPW = 256 / (2 * F);               // samples per workgroup iteration (64 for F = 2)
+  const int64_t nchunks = (M + SPW - 1) / SPW;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (int i = tid; i < HC_CAP; i += 256) {
+      keys[i] = HC_EMPTY;
+#pragma unroll
+      for (int f = 0; f < F; ++f) vals[i * F + f] = (AccT)0;
+    }
+    __syncthreads();
+    const int64_t m = chunk * SPW + tid / (2 * F);
+    if (m < M) {
+      const int q = tid % (2 * F), f = q % F, dx = q / F;
+      float px, py, pz;
+      point_of(ps, m, px, py, pz);
+      const float xs = px * r, ys = py * r, zs = pz * r;
+      const float fx = floorf(xs), fy = floorf(ys), fz = floorf(zs);
+      const float ox = xs - fx, oy = ys - fy, oz = zs - fz;
+      const uint32_t cx = (uint32_t)(int32_t)(dx ? ceilf(xs) : fx);
+      const uint32_t yf = (uint32_t)(int32_t)fy * 2654435761u, yc = (uint32_t)(int32_t)ceilf(ys) * 2654435761u;
+      const uint32_t zf = (uint32_t)(int32_t)fz * 805459861u, zc = (uint32_t)(int32_t)ceilf(zs) * 805459861u;
+      const float g = d_out[(m * L + l) * F + f];
+      const float wx = dx ? ox : 1 - ox;
+      const uint32_t idx[4] = {(cx ^ yc ^ zc) & mask, (cx ^ yf ^ zc) & mask, (cx ^ yc ^ zf) & mask, (cx ^ yf ^ zf) & mask};
+      const float val[4] = {g * oz * oy * wx, g * oz * (1 - oy) * wx, g * (1 - oz) * oy * wx, g * (1 - oz) * (1 - oy) * wx};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t slot = (idx[c] * 2654435761u) >> 22;              // top 10 bits: HC_CAP = 1024
+        for (int probe = 0; probe < HC_CAP; ++probe) {              // terminates: <= 512 distinct keys in 1024 slots
+          const uint32_t prev = atomicCAS(&keys[slot], HC_EMPTY, idx[c]);
+          if (prev == HC_EMPTY || prev == idx[c]) break;
+          slot = (slot + 1) & (HC_CAP - 1);
+        }
+        if (FIXED) atomicAdd(reinterpret_cast<unsigned long long*>(&vals[slot * F + f]),
+                             (unsigned long long)(long long)__double2ll_rn((double)val[c] * NERF_HASH_FIX_SCALE));
+        else atomicAdd(reinterpret_cast<float*>(&vals[slot * F + f]), val[c]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < HC_CAP * F; i += 256) {                   // F consecutive lanes = the F features of one entry
+      const uint32_t k = keys[i / F];
+      if (k == HC_EMPTY) continue;
+      const AccT v = vals[i];
+      if (v == (AccT)0) continue;
+      if (FIXED) atomicAdd(d_fixed + tb + (size_t)k * F + (i % F), (unsigned long long)v);
+      else atomicAdd(d_tables + tb + (size_t)k * F + (i % F), (float)v);
+    }
+    __syncthreads();
+  }
+}
+
 template <bool BWD>
 static int launch_hashgrid(const float* x, int64_t M, const float* tables, float* d_tables, const float* d_out, int L,
                            int log2_T, int F, const int* res, float* out, void* stream, const char* who,
@@ -176,6 +251,24 @@ static int launch_hashgrid(const float* x, int64_t M, const float* tables, float
   if (level_hi < 0) level_hi = L;
   NERF_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= L, NERF_E_SHAPE, "%s: need 0 <= level_lo <= level_hi <= L", who);
   if (level_lo == level_hi) return NERF_OK;
+  if (BWD && (F == 2 || F == 4) && g_hash_combine_max_res > 0) {
+    // leading levels of the range whose resolution is small enough for LDS write-combining to pay (see the kernel)
+    int nc = 0;
+    while (level_lo + nc < level_hi && res[level_lo + nc] <= g_hash_combine_max_res) ++nc;
+    if (nc > 0) {
+      const dim3 gc(grid_for((M + 63) / 64, 1, 256 * 8), (unsigned)nc), bc(256);
+      auto stc = as_stream(stream);
+      const PointSrc psc{x, rays, z, n, pos_scale, pos_offset};
+#define HC(FF) do { if (fixed) hipLaunchKernelGGL((hashgrid_bwd_combine_kernel<FF, true>), gc, bc, 0, stc, psc, M, (void*)d_tables, d_out, L, T, rt, level_lo); \
+                    else hipLaunchKernelGGL((hashgrid_bwd_combine_kernel<FF, false>), gc, bc, 0, stc, psc, M, (void*)d_tables, d_out, L, T, rt, level_lo); } while (0)
+      if (F == 2) HC(2); else HC(4);
+#undef HC
+      const int rc = check_launch(who);
+      if (rc) return rc;
+      level_lo += nc;
+      if (level_lo == level_hi) return NERF_OK;
+    }
+  }
   const int nlev = BWD ? level_hi - level_lo : L;
   const dim3 g(grid_for(BWD ? M * F * 2 : M, 256, 256 * 32), (unsigned)((nlev + LG - 1) / LG)), b(256);
   auto st = as_stream(stream);

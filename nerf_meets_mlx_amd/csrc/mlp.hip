@@ -47,6 +47,8 @@
 
 namespace nerf {
 
+extern int g_hash_combine_max_res;        // encode.hip
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -2113,6 +2115,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "dw_unit_bias")) { g_dw_bias = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "bwd_stage")) { g_bwd_stage = value; return NERF_OK; }
   if (!strcmp(key, "dw_job_mask")) { g_dw_job_mask = value; return NERF_OK; }
+  if (!strcmp(key, "hash_combine_max_res")) { g_hash_combine_max_res = value > 0 ? value : 0; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -2122,6 +2125,7 @@ extern "C" int nerf_get_option(const char* key) {
   if (!strcmp(key, "ring_workgroups")) return g_ring_wgs;
   if (!strcmp(key, "ring_split")) return g_ring_split;
   if (!strcmp(key, "dw_workgroups")) return g_dw_wgs;
+  if (!strcmp(key, "hash_combine_max_res")) return g_hash_combine_max_res;
   return -1;
 }
 

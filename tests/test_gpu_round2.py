@@ -243,34 +243,21 @@ def test_fp32_mode_backward_and_training_step():
 
 
 # ------------------------------------------------------------------------------ PSNR parity over a training run
-def test_psnr_parity_training_run():
-    """north_star: "PSNR within 0.1 dB of the MLX reference at equal iterations".  HIP Trainer (bf16 MFMA) and the fp32
-    oracle trainer (torch fp32 ops on the same device, only for speed) get identical rays, targets and importance
-    uniforms.  What can be asserted, and why (profiles/r02_psnr_*: two FP32 implementations, this repo's fp32 mode and the
-    fp32 oracle, sit 0.05 dB apart for ~1500 iterations and then drift +-1 dB apart: training is chaotic, held-out PSNR
-    itself swings by 1 dB between checkpoints):
-      (a) while the trajectories are still the same trajectory (first 300 iterations, every 100): |delta PSNR| <= 0.1 dB
-          (100 x 100 views, N_rand 2048: a configuration where neither network passes through the dead state of
-          DESIGN.md section 7 on the way -- with N_rand 4096 at 200 x 200 both trainers are dead at iteration 100 and
-          leave that state at different iterations, a bifurcation no tolerance can bridge);
-      (b) at EVERY checkpoint of a 2000-iteration run, on the SAME weights (the HIP trainer's): the bf16 HIP renderer and
-          the fp32 oracle renderer give the same held-out PSNR within 0.05 dB, and the two compute the same gradient of the
-          current batch (cosine >= 0.98 for both networks, losses within 2 %) -- equal arithmetic along the whole run;
-      (c) the run learns the scene: >= 20 dB held-out PSNR, so none of the above is a statement about untrained nets.
-    The configs[2] / configs[1]-scale runs (800^2 / 400^2, N_rand 1024, 5000 iterations) are tools/psnr_parity.py, logged
-    under profiles/."""
+def test_same_weights_parity_over_a_training_run():
+    """The arithmetic half of the north-star PSNR claim (the trajectory half is the paired ensemble of
+    tests/test_gpu_round3.py::test_psnr_paired_ensemble_bf16_vs_reference_arithmetic; round 2's 300-iteration lockstep check
+    against one oracle trajectory is gone: it was a statement about one chaotic trajectory and had been tuned to a
+    configuration where it passed).  At EVERY checkpoint of a 2000-iteration run of the bf16 HIP trainer, on the SAME
+    weights: the bf16 HIP renderer and the fp32 oracle renderer give the same held-out PSNR within 0.05 dB, and the two
+    compute the same gradient of the current batch (cosine >= 0.98 for both networks, losses within 2 %) -- equal
+    arithmetic along the whole run; and the run learns the scene (>= 20 dB held-out), so this is not a statement about
+    untrained networks.  The configs[2] / configs[1]-scale runs (800^2 / 400^2, N_rand 1024, 5000 iterations) are
+    tools/psnr_parity.py, logged under profiles/."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import psnr_parity
     show = lambda r: print("[psnr]", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
                                       if k.startswith(("iter", "psnr", "delta", "grad"))}, flush=True)
-    # (a) lockstep with the free-running oracle trainer while both are on one trajectory
-    early = psnr_parity.run(hw=100, n_rand=2048, iters=300, every=100, views=16, test_views=2, n_importance=128,
-                            oracle_device="cuda", eval_chunk=10000, emit=lambda r: show(r) if "iter" in r else None)
-    assert len(early) == 3
-    for r in early:
-        assert abs(r["delta_db"]) <= 0.1, r
-    assert early[-1]["psnr_hip"] > early[0]["psnr_hip"]                     # both are learning, not both dead
-    # (b) + (c): the HIP trainer runs on; the oracle is evaluated on ITS weights at every checkpoint
+    # the HIP trainer runs; the oracle is evaluated on ITS weights at every checkpoint
     recs = psnr_parity.run(hw=200, n_rand=4096, iters=2000, every=100, views=24, test_views=2, n_importance=128,
                            oracle_device="cuda", eval_chunk=20000, cross=True, oracle_until=0,
                            emit=lambda r: show(r) if "iter" in r else None)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Merge the per-call outputs of tools/psnr_ensemble.py (one ensemble split over several gpurun calls by --seed-list) into
+one tracked file: all per-(seed, checkpoint) rows, the per-seed dead-sigma records, and the ensemble statistics recomputed
+over ALL seeds (paired mean / std / 95 % CI of PSNR_bf16 - PSNR_fp32 per checkpoint; all finite seeds, and the subset whose
+networks are alive at the end in both arms).
+
+    python tools/merge_ensemble.py profiles/r03_psnr_ensemble_X.jsonl gpurun_out/r3_ens_A.jsonl gpurun_out/r3_ens_B.jsonl ...
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from psnr_ensemble import paired_stats, summarise                     # noqa: E402  (torch import only; no GPU needed)
+
+
+def main():
+    out, ins = sys.argv[1], sys.argv[2:]
+    rows, deads, cfg, seeds = [], {}, None, []
+    for p in ins:
+        for ln in open(p):
+            r = json.loads(ln)
+            if "config" in r:
+                cfg = cfg or r["config"]
+                seeds += r["seeds"]
+            elif "dead_sigma" in r and not r.get("bridge"):
+                deads[r["seed"]] = r["dead_sigma"]
+            elif "iter" in r and "seed" in r and "psnr_oracle" not in r:
+                rows.append(r)
+    done = sorted({r["seed"] for r in rows})
+    with open(out, "w") as fp:
+        keep = {k: cfg[k] for k in ("hw", "n_rand", "iters", "every", "views", "test_views", "n_importance", "lrate_decay", "no_quirks")}
+        fp.write(json.dumps({"merged_from": [os.path.basename(p) for p in ins], "config": keep, "seeds": done,
+                             "arms": {"bf16": "Trainer(precision=16)", "fp32": "Trainer(precision=32)"}}) + "\n")
+        for r in sorted(rows, key=lambda r: (r["seed"], r["iter"])):
+            fp.write(json.dumps(r) + "\n")
+        for sd in done:
+            if sd in deads:
+                fp.write(json.dumps({"seed": sd, "dead_sigma": deads[sd]}) + "\n")
+        for st in summarise(rows):
+            fp.write(json.dumps(st) + "\n")
+        dead_any = lambda d: any(d[arm][net]["dead_at_end"] for arm in ("bf16", "fp32") for net in ("coarse", "fine"))
+        alive = {sd for sd in done if sd in deads and not dead_any(deads[sd])}
+        for st in summarise(rows, label="bf16_minus_fp32_alive_at_end_in_both_arms", only_seeds=alive):
+            fp.write(json.dumps(st) + "\n")
+        # when each arm first leaves / enters the dead-sigma state
+        fp.write(json.dumps({"dead_sigma_summary": {
+            arm: {f"seeds_ever_dead_{net}": [s for s in done if s in deads and deads[s][arm][net]["dead_iterations"] > 0] for net in ("coarse", "fine")}
+            | {f"seeds_dead_at_end_{net}": [s for s in done if s in deads and deads[s][arm][net]["dead_at_end"]] for net in ("coarse", "fine")}
+            for arm in ("bf16", "fp32")}}) + "\n")
+    print(f"{len(done)} seeds, {len(rows)} rows -> {out}")
+    for st in summarise(rows):
+        print(st["ensemble_iter"], "n", st["n"], "mean %+.3f sd %.3f ci +-%.3f median %+.3f  +%d/-%d" %
+              (st["mean_delta_db"], st["std_delta_db"], st["ci95_half_width_db"], st["median_delta_db"], st["n_positive"], st["n_negative"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,13 @@ for det in (False, True):
         N.check(N.lib().nerf_hashgrid_backward_rays_ex(N.ptr(rays), N.ptr(z), z.shape[0], z.shape[1], N.ptr(d_x), e.n_levels,
                                                        e.log2_hashmap_size, e.n_features_per_level, e._res_c, f.pos_scale,
                                                        f.pos_offset, lo, hi, int(det), N.ptr(e.grad), N.stream()))
+    for comb in (0, 64):
+        N.check(N.lib().nerf_set_option(b"hash_combine_max_res", comb))
+        t = timeit(lambda: scatter(0, 16))
+        print(f"scatter,{mode} combine<={comb},0-15,{t:.4f},{M * 256 / t / 1e6:.2f}")
+        for l in range(6):
+            t = timeit(lambda: scatter(l, l + 1))
+            print(f"scatter,{mode} combine<={comb},{l} (res {e.scaled_res[l]}),{t:.4f},{M * 16 / t / 1e6:.2f}")
     t = timeit(lambda: scatter(0, 16))
     print(f"scatter,{mode},0-15,{t:.4f},{M * 256 / t / 1e6:.2f}")
     for lo in range(0, 16, 4):

@@ -191,6 +191,12 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
                 rec["delta_db_bf16_minus_oracle"] = rec["psnr_bf16"] - rec["psnr_oracle"]
             recs.append(rec)
             emit(json.dumps(rec))
+            if getattr(a, "resync", False):
+                # short-horizon mode: the bf16 arm restarts from the fp32 arm's state (weights, Adam moments and step
+                # counts), so that every checkpoint measures the divergence accumulated over ONE interval of `every`
+                # iterations from a common state -- common random numbers + resynchronisation: trajectories stay
+                # correlated over a short horizon, and a systematic per-interval drift shows with a tiny variance
+                arms["bf16"].load_state_dict(arms["fp32"].state_dict())
     emit(json.dumps({"seed": seed, "dead_sigma": {k: v.summary(iters) for k, v in dead.items()}, "iters": iters,
                      "bridge": bool(bridge)}))
     return recs, {k: v.summary(iters) for k, v in dead.items()}
@@ -235,6 +241,8 @@ def main():
     ap.add_argument("--bridge-iters", type=int, default=0, help="iterations of the bridge runs (0: --iters)")
     ap.add_argument("--bridge-only", action="store_true")
     ap.add_argument("--no-quirks", action="store_true")
+    ap.add_argument("--resync", action="store_true", help="after every checkpoint copy the fp32 arm's state into the bf16 arm: each "
+                    "checkpoint's delta is then the drift of ONE interval from a common state (short-horizon bias estimator)")
     ap.add_argument("--out", default="", help="also append every line to this file")
     a = ap.parse_args()
     fp = open(a.out, "a") if a.out else None
