@@ -304,6 +304,13 @@ __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fba
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = extra_w ? extra_w[32 * kt + prow(i) + 4 * h] * extra_s : 0.0f;
+    // the ReLU decisions of this k-tile (stored activations of the forward) are fetched BEFORE the MFMAs: with one wave per
+    // SIMD (128 KiB of LDS slabs per workgroup) nothing else hides a global-load latency, and the 128 MFMAs below take 4 us
+    float hm[16];
+    if (mask_row0 >= 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hm[i] = *store_row(const_cast<float*>(acts), tile, A_ROWS, mask_row0 + 32 * kt + prow(i) + 4 * h, col);
+    }
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       const Frag16 a = load_frag(wl, fbase + kt * NS + ns);
@@ -314,7 +321,7 @@ __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fba
     for (int i = 0; i < 16; ++i) {
       const int row = 32 * kt + prow(i) + 4 * h;
       float v = acc[i];
-      if (mask_row0 >= 0 && !(*store_row(const_cast<float*>(acts), tile, A_ROWS, mask_row0 + row, col) > 0.0f)) v = 0.0f;
+      if (mask_row0 >= 0 && !(hm[i] > 0.0f)) v = 0.0f;
       slab[row * 32 + col] = v;
       *store_row(dz, tile, Z_ROWS, zrow0 + row, col) = v;
     }
@@ -405,10 +412,10 @@ __global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
       for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.0f;
   float bsum[2] = {0.0f, 0.0f};
   const bool n1 = nt0 + 1 < jb.n_tiles, k1 = kt0 + 1 < jb.k_tiles;
-  for (int t = t_lo; t < t_hi; ++t) {
-    // lane (row r32, half h) reads samples 16 h .. 16 h + 15 of its feature row: MFMA step s pairs sample s (h = 0)
-    // with sample 16 + s (h = 1) in both operands
-    Frag16 za[2], hb[2];
+  // lane (row r32, half h) reads samples 16 h .. 16 h + 15 of its feature row: MFMA step s pairs sample s (h = 0) with sample
+  // 16 + s (h = 1) in both operands.  The next tile's four fragments are requested before this tile's 64 MFMAs (4096 cycles)
+  // so that their latency is covered by arithmetic instead of by the other wave of the SIMD alone.
+  auto load_tile = [&](int t, Frag16 (&za)[2], Frag16 (&hb)[2]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int row = jb.zrow0 + 32 * (nt0 + ((r == 0 || n1) ? r : 0)) + r32;
@@ -423,6 +430,12 @@ __global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const float4 v = src[q]; hb[c].w[4 * q] = v.x; hb[c].w[4 * q + 1] = v.y; hb[c].w[4 * q + 2] = v.z; hb[c].w[4 * q + 3] = v.w; }
     }
+  };
+  Frag16 za[2], hb[2], zan[2], hbn[2];
+  if (t_lo < t_hi) load_tile(t_lo, za, hb);
+  for (int t = t_lo; t < t_hi; ++t) {
+    const bool more = t + 1 < t_hi;
+    if (more) load_tile(t + 1, zan, hbn);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (kt0 == 0) {
@@ -434,6 +447,10 @@ __global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
 #pragma unroll
         for (int s = 0; s < 16; ++s)
           acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[r].w[s], hb[c].w[s], acc[r][c], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { za[r] = zan[r]; hb[r] = hbn[r]; }
     }
   }
 #pragma unroll

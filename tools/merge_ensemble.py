@@ -39,6 +39,11 @@ def main():
                 fp.write(json.dumps({"seed": sd, "dead_sigma": deads[sd]}) + "\n")
         for st in summarise(rows):
             fp.write(json.dumps(st) + "\n")
+        if any("psnr_bf16b" in r for r in rows):
+            for st in summarise(rows, "psnr_bf16b", "psnr_bf16", "null_bf16b_minus_bf16"):
+                fp.write(json.dumps(st) + "\n")
+            for st in summarise([r for r in rows if "psnr_bf16b" in r], label="bf16_minus_fp32_on_the_null_arm_seeds"):
+                fp.write(json.dumps(st) + "\n")
         dead_any = lambda d: any(d[arm][net]["dead_at_end"] for arm in ("bf16", "fp32") for net in ("coarse", "fine"))
         alive = {sd for sd in done if sd in deads and not dead_any(deads[sd])}
         for st in summarise(rows, label="bf16_minus_fp32_alive_at_end_in_both_arms", only_seeds=alive):
@@ -49,6 +54,10 @@ def main():
             | {f"seeds_dead_at_end_{net}": [s for s in done if s in deads and deads[s][arm][net]["dead_at_end"]] for net in ("coarse", "fine")}
             for arm in ("bf16", "fp32")}}) + "\n")
     print(f"{len(done)} seeds, {len(rows)} rows -> {out}")
+    if any("psnr_bf16b" in r for r in rows):
+        for st in summarise(rows, "psnr_bf16b", "psnr_bf16", "null"):
+            print("NULL", st["ensemble_iter"], "n", st["n"], "mean %+.3f sd %.3f ci +-%.3f median %+.3f  +%d/-%d" %
+                  (st["mean_delta_db"], st["std_delta_db"], st["ci95_half_width_db"], st["median_delta_db"], st["n_positive"], st["n_negative"]))
     for st in summarise(rows):
         print(st["ensemble_iter"], "n", st["n"], "mean %+.3f sd %.3f ci +-%.3f median %+.3f  +%d/-%d" %
               (st["mean_delta_db"], st["std_delta_db"], st["ci95_half_width_db"], st["median_delta_db"], st["n_positive"], st["n_negative"]))

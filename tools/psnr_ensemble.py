@@ -33,6 +33,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nerf_meets_mlx_amd import _native                                # noqa: E402
 from nerf_meets_mlx_amd.dataset import synthetic                      # noqa: E402
 from nerf_meets_mlx_amd.engine.trainer import Trainer                 # noqa: E402
 from nerf_meets_mlx_amd.rendering import ray                          # noqa: E402
@@ -126,6 +127,12 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
                               ref_quirks=quirks, precision=prec)
     arms = {"bf16": mk(16), "fp32": mk(32)}
     assert torch.equal(arms["bf16"].coarse.params, arms["fp32"].coarse.params)
+    if getattr(a, "null_arm", False):
+        # NULL arm: the SAME bf16 arithmetic, only the fp32 summation ORDER of the weight-gradient reduction differs (the
+        # dW kernel's split-K count, an A/B knob: 240 workgroups instead of one per CU) -- relative differences of 1e-7 per
+        # gradient.  delta(bf16b - bf16) is what "two runs of one arithmetic" look like under this training recipe: the
+        # yardstick for the bf16 - fp32 differences.
+        arms["bf16b"] = mk(16)
     dead = {k: DeadTracker() for k in arms}
     ot = None
     if bridge:
@@ -174,7 +181,11 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
         rays, target = lead.sample_batch()                       # (seed, rank, it) -> identical for both arms anyway
         u = lead.train_uniforms(rays.shape[0]) if a.n_importance > 0 else None
         for name, tr in arms.items():
+            if name == "bf16b":
+                _native.check(_native.lib().nerf_set_option(b"dw_workgroups", 240))
             losses = tr.train_step(rays, target, u)
+            if name == "bf16b":
+                _native.check(_native.lib().nerf_set_option(b"dw_workgroups", 0))
             if it % a.dead_every == 0 or it == iters:
                 dead[name].update(it, losses, target, quirks)
         if ot is not None:
@@ -185,6 +196,9 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
             rec = {"seed": seed, "iter": it, "psnr_bf16": psnr_of(arms["bf16"]), "psnr_fp32": psnr_of(arms["fp32"]),
                    "elapsed_s": round(time.time() - t0, 1)}
             rec["delta_db"] = rec["psnr_bf16"] - rec["psnr_fp32"]
+            if "bf16b" in arms:
+                rec["psnr_bf16b"] = psnr_of(arms["bf16b"])
+                rec["delta_db_null"] = rec["psnr_bf16b"] - rec["psnr_bf16"]
             if ot is not None:
                 rec["psnr_oracle"] = psnr_oracle()
                 rec["delta_db_fp32_minus_oracle"] = rec["psnr_fp32"] - rec["psnr_oracle"]
@@ -241,6 +255,8 @@ def main():
     ap.add_argument("--bridge-iters", type=int, default=0, help="iterations of the bridge runs (0: --iters)")
     ap.add_argument("--bridge-only", action="store_true")
     ap.add_argument("--no-quirks", action="store_true")
+    ap.add_argument("--null-arm", action="store_true", help="third arm: bf16 again with another fp32 summation order in dW (the "
+                    "noise floor of this training recipe: what two runs of ONE arithmetic look like)")
     ap.add_argument("--resync", action="store_true", help="after every checkpoint copy the fp32 arm's state into the bf16 arm: each "
                     "checkpoint's delta is then the drift of ONE interval from a common state (short-horizon bias estimator)")
     ap.add_argument("--out", default="", help="also append every line to this file")
@@ -270,6 +286,9 @@ def main():
             deads[sd] = dsum
         for st in summarise(recs):
             emit(json.dumps(st))
+        if a.null_arm:
+            for st in summarise(recs, "psnr_bf16b", "psnr_bf16", "null_bf16b_minus_bf16"):
+                emit(json.dumps(st))
         dead_any = lambda d: any(d[arm][net]["dead_at_end"] for arm in ("bf16", "fp32") for net in ("coarse", "fine"))
         alive = {sd for sd, d in deads.items() if not dead_any(d)}
         for st in summarise(recs, label="bf16_minus_fp32_alive_at_end_in_both_arms", only_seeds=alive):
