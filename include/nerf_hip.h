@@ -150,6 +150,9 @@ int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, in
  * all-reduce of their slice of d_tables on another stream), and optionally DETERMINISTIC: fixed_point = 1 makes d_tables
  * an int64 [L,T,F] array of 2^-52 fixed-point accumulators added with integer atomics (associative: the result does not
  * depend on the order the memory side serves the requests; float atomics do).  nerf_adam_step_ex consumes either form.  */
+int nerf_hashgrid_backward_ex(const float* x, int64_t M, const float* d_out, int L, int log2_T, int F,
+                              const int* resolutions_host, int level_lo, int level_hi, int fixed_point, void* d_tables,
+                              void* stream);
 int nerf_hashgrid_backward_rays_ex(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,
                                    int log2_T, int F, const int* resolutions_host, float pos_scale, float pos_offset,
                                    int level_lo, int level_hi, int fixed_point, void* d_tables, void* stream);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "nerf_ngp_encode": (_I, [_P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), _I, C.c_float, C.c_float, _P, _P, _P]),
     "nerf_ngp_query_fused": (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), _I, C.c_float, C.c_float, _P, _P, _P]),
     "nerf_hashgrid_backward_rays": (_I, [_P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), C.c_float, C.c_float, _P, _P]),
+    "nerf_hashgrid_backward_ex": (_I, [_P, _I64, _P, _I, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _P, _P]),
     "nerf_hashgrid_backward_rays_ex": (_I, [_P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), C.c_float, C.c_float, _I, _I, _I, _P, _P]),
     "nerf_composite_forward": (_I, [_P, _P, _P, _I64, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P]),
     "nerf_composite_backward": (_I, [_P, _P, _P, _I64, _I, _F, _P, _I, _P, _P, _P, _P, _P]),

@@ -165,10 +165,14 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t 
 // addends hit few distinct table entries, and every workgroup of the launch hammers the same few thousand entries of
 // that level (measured: level 0 runs at 28 G atomics/s against 70 G for the fine levels).  Here the addends are first
 // accumulated in a small open-addressing table in LDS (keys: entry index; LDS atomics), then each distinct (entry,
-// feature) is added to the global table ONCE.  In FIXED mode the LDS accumulators are the same int64 fixed-point numbers
-// as the global ones: integer addition is associative, so the result is bit-identical to the direct kernel's.
+// feature) is added to the global table ONCE.  The thread whose compare-and-swap claims an empty slot appends the slot
+// to a list, and the flush walks only that list and leaves the slots it visits empty again: the cost per iteration is
+// proportional to the number of DISTINCT entries, not to the table size.  A key that finds no slot within HC_PROBES steps
+// goes to the global table directly (adds commute).  In FIXED mode the LDS accumulators are the same int64 fixed-point
+// numbers as the global ones: integer addition is associative, so the result is bit-identical to the direct kernel's.
 int g_hash_combine_max_res = 64;    // A/B knob (nerf_set_option "hash_combine_max_res"): levels with N_l <= this go through LDS; 0 = off
 constexpr int HC_CAP = 1024;                       // slots; at most 64 samples x 8 corners = 512 distinct keys per iteration
+constexpr int HC_PROBES = 32;
 constexpr uint32_t HC_EMPTY = 0xFFFFFFFFu;
 template <int F, bool FIXED>
 __global__ void __launch_bounds__(256) hashgrid_bwd_combine_kernel(PointSrc ps, int64_t M, void* __restrict__ d_tables_v,
@@ -176,7 +180,9 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_combine_kernel(PointSrc ps, 
                                                                    ResTab rt, int level_lo) {
   typedef typename std::conditional<FIXED, unsigned long long, float>::type AccT;
   __shared__ uint32_t keys[HC_CAP];
+  __shared__ uint32_t list[HC_CAP];
   __shared__ AccT vals[HC_CAP * F];
+  __shared__ uint32_t count[2];
   const int l = level_lo + blockIdx.y;
   const uint32_t mask = T - 1;
   const float r = rt.res[l];
@@ -186,13 +192,15 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_combine_kernel(PointSrc ps, 
   const int tid = threadIdx.x;
   constexpr int SPW = 256 / (2 * F);               // samples per workgroup iteration (64 for F = 2)
   const int64_t nchunks = (M + SPW - 1) / SPW;
-  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    for (int i = tid; i < HC_CAP; i += 256) {
-      keys[i] = HC_EMPTY;
+  for (int i = tid; i < HC_CAP; i += 256) {
+    keys[i] = HC_EMPTY;
 #pragma unroll
-      for (int f = 0; f < F; ++f) vals[i * F + f] = (AccT)0;
-    }
-    __syncthreads();
+    for (int f = 0; f < F; ++f) vals[i * F + f] = (AccT)0;
+  }
+  if (tid < 2) count[tid] = 0;
+  __syncthreads();
+  int par = 0;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, par ^= 1) {
     const int64_t m = chunk * SPW + tid / (2 * F);
     if (m < M) {
       const int q = tid % (2 * F), f = q % F, dx = q / F;
@@ -211,24 +219,35 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_combine_kernel(PointSrc ps, 
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         uint32_t slot = (idx[c] * 2654435761u) >> 22;              // top 10 bits: HC_CAP = 1024
-        for (int probe = 0; probe < HC_CAP; ++probe) {              // terminates: <= 512 distinct keys in 1024 slots
+        bool found = false;
+        for (int probe = 0; probe < HC_PROBES; ++probe) {
           const uint32_t prev = atomicCAS(&keys[slot], HC_EMPTY, idx[c]);
-          if (prev == HC_EMPTY || prev == idx[c]) break;
+          if (prev == HC_EMPTY) { list[atomicAdd(&count[par], 1u)] = slot; found = true; break; }     // this thread claimed the slot
+          if (prev == idx[c]) { found = true; break; }
           slot = (slot + 1) & (HC_CAP - 1);
         }
-        if (FIXED) atomicAdd(reinterpret_cast<unsigned long long*>(&vals[slot * F + f]),
-                             (unsigned long long)(long long)__double2ll_rn((double)val[c] * NERF_HASH_FIX_SCALE));
-        else atomicAdd(reinterpret_cast<float*>(&vals[slot * F + f]), val[c]);
+        if (FIXED) {
+          const unsigned long long q64 = (unsigned long long)(long long)__double2ll_rn((double)val[c] * NERF_HASH_FIX_SCALE);
+          if (found) atomicAdd(reinterpret_cast<unsigned long long*>(&vals[slot * F + f]), q64);
+          else atomicAdd(d_fixed + tb + (size_t)idx[c] * F + f, q64);
+        } else {
+          if (found) atomicAdd(reinterpret_cast<float*>(&vals[slot * F + f]), val[c]);
+          else atomicAdd(d_tables + tb + (size_t)idx[c] * F + f, val[c]);
+        }
       }
     }
     __syncthreads();
-    for (int i = tid; i < HC_CAP * F; i += 256) {                   // F consecutive lanes = the F features of one entry
-      const uint32_t k = keys[i / F];
-      if (k == HC_EMPTY) continue;
-      const AccT v = vals[i];
-      if (v == (AccT)0) continue;
-      if (FIXED) atomicAdd(d_fixed + tb + (size_t)k * F + (i % F), (unsigned long long)v);
-      else atomicAdd(d_tables + tb + (size_t)k * F + (i % F), (float)v);
+    const int n = (int)count[par] * F;
+    if (tid == 0) count[par ^ 1] = 0;                               // last read before the previous barrier
+    for (int i = tid; i < n; i += 256) {                            // F consecutive lanes = the F features of one entry
+      const uint32_t slot = list[i / F];
+      const int f = i % F;
+      const uint32_t k = keys[slot];
+      const AccT v = vals[slot * F + f];
+      vals[slot * F + f] = (AccT)0;
+      if (f == F - 1) keys[slot] = HC_EMPTY;                        // the F lanes of a slot sit in one wave: all have read k
+      if (FIXED) atomicAdd(d_fixed + tb + (size_t)k * F + f, (unsigned long long)v);
+      else atomicAdd(d_tables + tb + (size_t)k * F + f, (float)v);
     }
     __syncthreads();
   }
@@ -347,6 +366,16 @@ extern "C" int nerf_ngp_encode(const float* rays, const float* z, int64_t B, int
   hipLaunchKernelGGL(ngp_dir_rows_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), rays, z, n, M, sh_degree,
                      x_out, stride, L * F, pts_out, pos_scale, pos_offset);
   return check_launch("nerf_ngp_encode");
+}
+
+extern "C" int nerf_hashgrid_backward_ex(const float* x, int64_t M, const float* d_out, int L, int log2_T, int F,
+                                         const int* resolutions_host, int level_lo, int level_hi, int fixed_point,
+                                         void* d_tables, void* stream) {
+  NERF_REQUIRE(d_out && d_tables, NERF_E_NULL, "nerf_hashgrid_backward_ex: d_out/d_tables is NULL");
+  NERF_REQUIRE(fixed_point == 0 || fixed_point == 1, NERF_E_UNSUPPORTED, "nerf_hashgrid_backward_ex: fixed_point must be 0 or 1");
+  return launch_hashgrid<true>(x, M, nullptr, static_cast<float*>(d_tables), d_out, L, log2_T, F, resolutions_host, nullptr,
+                               stream, "nerf_hashgrid_backward_ex", nullptr, nullptr, 1, 0, 1.0f, 0.0f, level_lo, level_hi,
+                               fixed_point != 0);
 }
 
 extern "C" int nerf_hashgrid_backward_rays_ex(const float* rays, const float* z, int64_t B, int n, const float* d_out, int L,

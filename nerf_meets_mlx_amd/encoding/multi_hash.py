@@ -41,8 +41,10 @@ class MultiHashEncoding(Encoding):
         return out
 
     def backward(self, in_array: torch.Tensor, d_out: torch.Tensor):
-        """self.grad += d(out)/d(tables)^T d_out (float atomics)."""
+        """self.grad += d(out)/d(tables)^T d_out.  A float32 `self.grad` is accumulated with float atomics; an int64
+        `self.grad` (engine/ngp.py, deterministic mode) holds 2^-52 fixed-point accumulators added with integer atomics."""
         x, g = N.f32(in_array), N.f32(d_out)
-        N.check(N.lib().nerf_hashgrid_backward(N.ptr(x), x.shape[0], N.ptr(g), self.n_levels, self.log2_hashmap_size,
-                                               self.n_features_per_level, self._res_c, N.ptr(self.grad), N.stream()))
+        N.check(N.lib().nerf_hashgrid_backward_ex(N.ptr(x), x.shape[0], N.ptr(g), self.n_levels, self.log2_hashmap_size,
+                                                  self.n_features_per_level, self._res_c, 0, self.n_levels,
+                                                  int(self.grad.dtype == torch.int64), N.ptr(self.grad), N.stream()))
         return self.grad

@@ -51,7 +51,7 @@ class HashNeRF:
 
     def __init__(self, device="cuda", seed: int = 0, n_levels: int = 16, min_res: int = 16, max_res: int = 2048,
                  n_features_per_level: int = 2, log2_hashmap_size: int = 19, hash_init_scale: float = 1e-4,
-                 bound: Optional[float] = 1.5, deterministic: bool = False, level_groups: int = 4):
+                 bound: Optional[float] = 1.5, deterministic: bool = True, level_groups: int = 4):
         """bound: half-extent of the scene box that is mapped onto the grid's unit cube before hashing
         (x' = (x + bound) / (2 bound)), so that N_l is the level's resolution ACROSS the scene (without it the reference's
         x * N_l sees world units: 3 x finer cells, and a 24-view run memorises its training rays: held-out PSNR 13.8 dB
@@ -63,8 +63,9 @@ class HashNeRF:
         self.mlp = NeRF(n_layers=2, width_layers=64, channel_input=32, channel_input_views=16,
                         list_skip_connection_layers=[], is_use_view_directions=True, device=device, seed=seed)
         self.pos_scale, self.pos_offset = (1.0, 0.0) if bound is None else (1.0 / (2.0 * bound), 0.5)
-        # table-gradient accumulator: float32 (float atomics: fast, order-dependent rounding) or int64 2^-52 fixed point
-        # (integer atomics: bit-reproducible).  It is cleared by the Adam pass that consumes it, never by a memset.
+        # table-gradient accumulator: int64 2^-52 fixed point added with integer atomics (the default: bit-reproducible, and
+        # measured no slower than float atomics -- both are bound by the atomic request rate, profiles/r03_ngp_scatter.csv)
+        # or float32 (float atomics, order-dependent rounding).  The Adam pass that consumes it clears it: no memset.
         self.deterministic = bool(deterministic)
         if self.deterministic:
             self.enc.grad = torch.zeros(self.enc.tables.shape, dtype=torch.int64, device=self.enc.tables.device)
@@ -121,6 +122,11 @@ class HashNeRF:
                                              N.stream()))
         return raw
 
+    def table_grad(self) -> torch.Tensor:
+        """The accumulated table gradient as float32 [L,T,F] (a copy when the accumulators are int64 fixed point)."""
+        g = self.enc.grad
+        return (g.double() * 2.0 ** -52).float() if g.dtype == torch.int64 else g
+
     def backward(self, d_raw: torch.Tensor, accumulate: bool = False):
         """(MLP gradient [13188], table gradient [L,T,F]: float32, or int64 2^-52 fixed point when deterministic) of the
         last query(train=True).  accumulate=True adds into the gradient buffer as it stands (NGPTrainer: the Adam pass that
@@ -133,8 +139,6 @@ class HashNeRF:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if self._rz is None:                                 # unfused rows: positions were kept by features()
-            if self.deterministic:
-                raise ValueError("HashNeRF(deterministic=True) needs the fused query (positions from rays / depths)")
             e.backward(self._pts, d_x)
             if self.on_group_done is not None:
                 self.on_group_done(0, e.n_levels)

@@ -382,14 +382,9 @@ def test_checkpoint_npz_roundtrip_continues(tmp_path, kind, shared):
         for k in x:
             assert abs(float(x[k]) - float(y[k])) <= 1e-5 * abs(float(x[k])), (k, float(x[k]), float(y[k]))
     for k, ma in a._checkpoint_buffers().items():
-        if kind == "nerf":
-            # the 8 x 256 trainer is bit-reproducible since the split-K partial tiles are reduced in a fixed order
-            assert torch.equal(ma.params, b._checkpoint_buffers()[k].params), k
-        else:
-            diff = (ma.params - b._checkpoint_buffers()[k].params).abs()
-            # hash-table gradients are scattered with float atomics (order-dependent rounding), and Adam steps by
-            # lr * m / (sqrt(v) + eps): for an entry whose gradient is zero up to that noise the ratio is noise of order one
-            assert float(diff.max()) < 1e-3 and float(diff.mean()) < 1e-6, (k, float(diff.max()), float(diff.mean()))
+        # both trainers are bit-reproducible: the 8 x 256 one since its split-K partial tiles are reduced in a fixed order, the
+        # hash-grid one since its table gradient is accumulated in int64 fixed point with integer atomics (the default)
+        assert torch.equal(ma.params, b._checkpoint_buffers()[k].params), (kind, k)
     # state_dict round trip in memory too
     c = _mini_trainer(kind, shared)
     c.load_state_dict(a.state_dict())

@@ -2,13 +2,13 @@
 # Extra PMC passes (own runs, counters only): matrix-pipe busy cycles + GPU active cycles, LDS conflicts.
 set -e
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/pmc_mfma.log 2>&1
 echo mfma done
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_lds -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/pmc_lds.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_lds -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/pmc_lds.log 2>&1
 echo lds done
 python - <<PY
 import csv, glob, statistics, collections
