@@ -116,6 +116,24 @@ __device__ __forceinline__ Frag16 load_frag(const float4* __restrict__ lane_base
   for (int j = 0; j < 4; ++j) { const float4 v = fp[j]; r.w[4 * j] = v.x; r.w[4 * j + 1] = v.y; r.w[4 * j + 2] = v.z; r.w[4 * j + 3] = v.w; }
   return r;
 }
+// The same fragment as four 128-bit registers loaded by INLINE-ASM global loads, for the weight stream of the chain kernels.
+// hipcc's scheduler, at 250+ live registers, sinks ordinary loads to just before their first use (load; s_waitcnt vmcnt(0);
+// 4 MFMAs; load; ... -- every L2 round trip exposed, one wave per SIMD, nothing else to issue): measured 40-60 % of the
+// fp32 matrix peak.  With asm loads the issue point is ours: the NEXT fragment is requested before the 16 MFMAs (1024
+// cycles) of the current one, and frag_wait -- the only place its registers become visible to the compiler ("+v") -- sits
+// behind them.  s_waitcnt vmcnt(0) also drains whatever the compiler itself has in flight: always safe, never too early.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct FragQ { f32x4 q[4]; };
+__device__ __forceinline__ void frag_issue(FragQ& f, const float4* __restrict__ lane_base, int frag) {
+  const float4* p = lane_base + (int64_t)frag * 256;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.q[0]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.q[1]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.q[2]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.q[3]) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void frag_wait(FragQ& f) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.q[0]), "+v"(f.q[1]), "+v"(f.q[2]), "+v"(f.q[3]) : : "memory");
+}
 __device__ __forceinline__ float* store_row(float* base, int64_t tile, int rows, int row, int col) {
   return base + ((tile * rows + row) * 32 + col);
 }
@@ -126,15 +144,25 @@ template <int KT, bool RELU>
 __device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fbase, const float* __restrict__ bias, int NT,
                                           const f32x16 (&in)[KT], float* slab, int col, int h, float* sink, int64_t tile,
                                           int sink_row0) {
+  // The weight fragments of a layer are consecutive in the stream: the NEXT fragment (4 KiB from L2) is requested before
+  // the 16 MFMAs (1024 cycles) of the current one.  (The last prefetch of a layer reads the first fragment of whatever
+  // follows in the packed image: in bounds, unused.)
+  FragQ cur, nxt;
+  frag_issue(cur, wl, fbase);
+  frag_wait(cur);
   for (int nt = 0; nt < NT; ++nt) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = bias[32 * nt + prow(i) + 4 * h];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      const Frag16 a = load_frag(wl, fbase + nt * KT + kt);
+      frag_issue(nxt, wl, fbase + nt * KT + kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w[i], in[kt][i], acc, 0, 0, 0);
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.q[i >> 2][i & 3], in[kt][i], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_wait(nxt);
+      cur = nxt;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -300,6 +328,9 @@ template <int NS>
 __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fbase, int KT, const f32x16 (&in)[NS],
                                           float* slab, int col, int h, const float* __restrict__ acts, float* dz,
                                           int64_t tile, int mask_row0, int zrow0, const float* extra_w, float extra_s) {
+  FragQ cur, nxt;
+  frag_issue(cur, wl, fbase);
+  frag_wait(cur);
   for (int kt = 0; kt < KT; ++kt) {
     f32x16 acc;
 #pragma unroll
@@ -313,9 +344,13 @@ __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fba
     }
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      const Frag16 a = load_frag(wl, fbase + kt * NS + ns);
+      frag_issue(nxt, wl, fbase + kt * NS + ns + 1);                       // prefetch: see layer_fwd
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w[i], in[ns][i], acc, 0, 0, 0);
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.q[i >> 2][i & 3], in[ns][i], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_wait(nxt);
+      cur = nxt;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

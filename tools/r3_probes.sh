@@ -5,15 +5,15 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r03p
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_round3.py -m gpu -q -x -k "ngp or two_streams" > $O/t.log 2>&1; echo "pytest rc=$?"; tail -3 $O/t.log
+python -m pytest tests -m gpu -q > $O/t.log 2>&1; echo "pytest rc=$?"; tail -6 $O/t.log
 python tools/probe_ngp_scatter.py > $O/ngp_scatter.csv 2> $O/ngp_scatter.err; echo "ngp rc=$?"; grep -E "0-15|train_step|adam" $O/ngp_scatter.csv
 H=tools/diag/handoff_probe
 : > $O/handoff.csv
-for a in "128 16 2 256 0 16" "128 16 1 256 0 16" "128 16 3 256 0 16" "128 32 2 256 0 16" "64 8 2 256 0 16" "128 16 2 256 0 8" "8192 16 2 256 0 16" "32768 16 2 256 0 16" "128 16 2 256 800 16"; do
+for a in "128 16 2 256 0 16" "128 16 1 256 0 16" "128 16 3 256 0 16" "128 32 2 256 0 16" "64 8 2 256 0 16" "128 16 2 256 0 8" "1024 128 2 256 0 16" "8192 128 2 256 0 16" "128 16 2 256 800 16"; do
   timeout -k 5 120 $H $a >> $O/handoff.csv 2>&1 || echo "handoff $a rc=$?"
 done
 cat $O/handoff.csv | grep -v ring_KiB | awk -F, '{print $1,$2,$3,$5,$6,$7,"ms",$10,"chipGB/s",$12,"xcdGB/s",$13,"cuGB/s",$14,"bad",$15,"err",$16}' | awk 'NR%3==0'
-for cfg in "128 16 2 64 0 16" "32768 16 2 64 0 16"; do
+for cfg in "128 16 2 64 0 16" "8192 128 2 64 0 16"; do
   tag=$(echo $cfg | tr ' ' '_')
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$tag -- $H $cfg > $O/pmc_fetch_$tag.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$tag -- $H $cfg > $O/pmc_write_$tag.log 2>&1
