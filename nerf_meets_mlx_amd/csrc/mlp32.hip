@@ -131,6 +131,12 @@ __device__ __forceinline__ void frag_issue(FragQ& f, const float4* __restrict__ 
   asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.q[2]) : "v"(p) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.q[3]) : "v"(p) : "memory");
 }
+__device__ __forceinline__ void frag_issue_at(FragQ& f, const float* __restrict__ p) {       // 16 consecutive floats per lane
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.q[0]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.q[1]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.q[2]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.q[3]) : "v"(p) : "memory");
+}
 __device__ __forceinline__ void frag_wait(FragQ& f) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.q[0]), "+v"(f.q[1]), "+v"(f.q[2]), "+v"(f.q[3]) : : "memory");
 }
@@ -420,7 +426,7 @@ struct DwArgs32 {
 };
 
 // one wave = one unit: a 64 x 64 block (2 x 2 MFMA tiles) of one job's dW over one slice of the sample tiles
-__global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
+__global__ void __launch_bounds__(256, 2) mlp32_dw_kernel(DwArgs32 a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r32 = lane & 31, h = lane >> 5;
   const int unit = blockIdx.x * 4 + wv;
@@ -450,40 +456,43 @@ __global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
   // lane (row r32, half h) reads samples 16 h .. 16 h + 15 of its feature row: MFMA step s pairs sample s (h = 0) with sample
   // 16 + s (h = 1) in both operands.  The next tile's four fragments are requested before this tile's 64 MFMAs (4096 cycles)
   // so that their latency is covered by arithmetic instead of by the other wave of the SIMD alone.
-  auto load_tile = [&](int t, Frag16 (&za)[2], Frag16 (&hb)[2]) {
+  auto issue_tile = [&](int t, FragQ (&za)[2], FragQ (&hb)[2]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int row = jb.zrow0 + 32 * (nt0 + ((r == 0 || n1) ? r : 0)) + r32;
-      const float4* src = reinterpret_cast<const float4*>(a.dz + (((int64_t)t * Z_ROWS + row) * 32 + 16 * h));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const float4 v = src[q]; za[r].w[4 * q] = v.x; za[r].w[4 * q + 1] = v.y; za[r].w[4 * q + 2] = v.z; za[r].w[4 * q + 3] = v.w; }
+      frag_issue_at(za[r], a.dz + (((int64_t)t * Z_ROWS + row) * 32 + 16 * h));
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int row = jb.arow0 + 32 * (kt0 + ((c == 0 || k1) ? c : 0)) + r32;
-      const float4* src = reinterpret_cast<const float4*>(a.acts + (((int64_t)t * A_ROWS + row) * 32 + 16 * h));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const float4 v = src[q]; hb[c].w[4 * q] = v.x; hb[c].w[4 * q + 1] = v.y; hb[c].w[4 * q + 2] = v.z; hb[c].w[4 * q + 3] = v.w; }
+      frag_issue_at(hb[c], a.acts + (((int64_t)t * A_ROWS + row) * 32 + 16 * h));
     }
   };
-  Frag16 za[2], hb[2], zan[2], hbn[2];
-  if (t_lo < t_hi) load_tile(t_lo, za, hb);
+  // asm loads (frag_issue_at / frag_wait): the next tile's four fragments are in flight during this tile's 64 MFMAs
+  FragQ za[2], hb[2], zan[2], hbn[2];
+  if (t_lo < t_hi) {
+    issue_tile(t_lo, za, hb);
+    frag_wait(za[0]); frag_wait(za[1]); frag_wait(hb[0]); frag_wait(hb[1]);
+  }
   for (int t = t_lo; t < t_hi; ++t) {
     const bool more = t + 1 < t_hi;
-    if (more) load_tile(t + 1, zan, hbn);
+    if (more) issue_tile(t + 1, zan, hbn);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (kt0 == 0) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) bsum[r] += za[r].w[s];
+        for (int s = 0; s < 16; ++s) bsum[r] += za[r].q[s >> 2][s & 3];
       }
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int s = 0; s < 16; ++s)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[r].w[s], hb[c].w[s], acc[r][c], 0, 0, 0);
+          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[r].q[s >> 2][s & 3], hb[c].q[s >> 2][s & 3], acc[r][c], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (more) {
+      frag_wait(zan[0]); frag_wait(zan[1]); frag_wait(hbn[0]); frag_wait(hbn[1]);
 #pragma unroll
       for (int r = 0; r < 2; ++r) { za[r] = zan[r]; hb[r] = hbn[r]; }
     }
