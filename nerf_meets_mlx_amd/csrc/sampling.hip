@@ -49,14 +49,10 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
                                                          int64_t* __restrict__ inds_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // per wave: [pad0 | coarse z (n) | new z (P)] [cdf (n+1) | zmid (n+1)]; pad0 makes the new-depth list 16-byte aligned
-  // (ds_read_b128 sweeps in the rank sort below)
-  const int pad0 = (4 - (n & 3)) & 3;
-  const int all_len = (pad0 + n + P + 3) & ~3;
-  const int per_wave = all_len + (((n + 1) * 2 + 3) & ~3);
-  float* s_all = smem + wv * per_wave + pad0;
-  float* s_cdf = smem + wv * per_wave + all_len;
+  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3);
+  float* s_cdf = smem + wv * per_wave;
   float* s_zmid = s_cdf + (n + 1);
+  float* s_all = s_zmid + (n + 1);
   for (int64_t ray = blockIdx.x * 4 + wv; ray < B; ray += (int64_t)gridDim.x * 4) {
     const float* zr = z + ray * n;
     const float* wr = w + ray * n;
@@ -130,49 +126,22 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
       bool asc = true;
       for (int i = lane; i + 1 < n; i += WAVE) asc = asc && (s_all[i] <= s_all[i + 1]);
       if (__all(asc)) {
-        // Sort of the N new depths by RANK instead of by a bitonic network: every lane counts, for each of its keys, the
-        // keys that precede it (value, then position) in one sweep over the list with broadcast ds_read_b128 reads -- N / 4
-        // LDS instructions and no barrier, against 28 dependent exchange stages (2 reads + 2 writes + a wave barrier each)
-        // of the 128-key network, which was 58 of the kernel's 93 us per 32 768-ray chunk.  The ranks are a permutation of
-        // 0..N-1 (ties broken by position; the +inf padding never precedes a real key), written back in place once
-        // every lane has finished reading.
-        for (int i = N + lane; i < P; i += WAVE) s_new[i] = __builtin_inff();          // padding up to P >= N (P % 4 == 0 or P == 2)
+        for (int i = N + lane; i < P; i += WAVE) s_new[i] = __builtin_inff();          // pad to a power of two
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        {
-          float mine[8]; int rk[8];                           // N <= 512 = 8 keys per lane
-          const int per = (N + WAVE - 1) / WAVE;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) { const int j = lane + c * WAVE; mine[c] = (c < per && j < N) ? s_new[j] : __builtin_inff(); rk[c] = 0; }
-          const bool vec4 = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(s_new) & 15) == 0);
-          if (vec4) {
-            for (int k = 0; k < P; k += 4) {
-              const float4 o = *reinterpret_cast<const float4*>(s_new + k);
-#pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                if (c < per) {
-                  const int j = lane + c * WAVE;
-                  const float v = mine[c];
-                  rk[c] += (int)(o.x < v || (o.x == v && k < j)) + (int)(o.y < v || (o.y == v && k + 1 < j)) +
-                           (int)(o.z < v || (o.z == v && k + 2 < j)) + (int)(o.w < v || (o.w == v && k + 3 < j));
-                }
-              }
+        for (int k = 2; k <= P; k <<= 1) {
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int pi = lane; pi < (P >> 1); pi += WAVE) {
+              const int i = ((pi & ~(j - 1)) << 1) | (pi & (j - 1));
+              const int q = i | j;
+              const float a = s_new[i], b = s_new[q];
+              const bool up = (i & k) == 0;
+              if ((a > b) == up) { s_new[i] = b; s_new[q] = a; }
             }
-          } else {
-            for (int k = 0; k < N; ++k) {
-              const float o = s_new[k];
-#pragma unroll
-              for (int c = 0; c < 8; ++c)
-                if (c < per) { const int j = lane + c * WAVE; rk[c] += (int)(o < mine[c] || (o == mine[c] && k < j)); }
-            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
           }
-          __builtin_amdgcn_s_waitcnt(0);
-          __builtin_amdgcn_wave_barrier();                     // every lane has read the unsorted list
-#pragma unroll
-          for (int c = 0; c < 8; ++c) { const int j = lane + c * WAVE; if (c < per && j < N) s_new[rk[c]] = mine[c]; }
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
         // ties: coarse depths first.  rank(z_i) = i + #{new < z_i};  rank(new_j) = j + #{z <= new_j}
         for (int i = lane; i < n; i += WAVE) {
           const float v = s_all[i];
@@ -242,8 +211,7 @@ extern "C" int nerf_importance_sample(const float* z, const float* weights, cons
   NERF_REQUIRE(z && weights && u, NERF_E_NULL, "nerf_importance_sample: z/weights/u is NULL");
   int P = 2;
   while (P < N) P <<= 1;                                  // bitonic sort width of the new depths
-  const int pad0 = (4 - (n & 3)) & 3;
-  const int per_wave = ((pad0 + n + P + 3) & ~3) + (((n + 1) * 2 + 3) & ~3);
+  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3);
   const size_t lds = (size_t)per_wave * 4 * sizeof(float);
   const int grid = (int)((B + 3) / 4 > 256 * 8 ? 256 * 8 : (B + 3) / 4);
   const int ch = (n + 63) / 64;
