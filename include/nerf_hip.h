@@ -320,6 +320,9 @@ int nerf_comm_destroy(void* comm);
  *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)
  *   "hash_combine_max_res"  table-gradient scatter: levels with N_l <= this value (default 64) accumulate in LDS first and
  *                     add each distinct table entry once (coarse levels collide heavily); 0 = every level directly
+ *   "ngp_ray_major"   fused configs[4] inference query: 1 (default) a 32-sample tile is one depth of 32 adjacent rays (the
+ *                     lanes of a gather share cells at 13 of 16 levels when rays are neighbouring pixels), 0 = 32
+ *                     consecutive depths of one ray.  Same values per sample either way.
  *   "ring_split"      1 (default): one 8-wave workgroup per CU behind a 128 KiB weight ring; 2: two independent 4-wave
  *                     workgroups behind 64 KiB rings (training forward / chain only; measured slower)
  * nerf_get_option returns the current value of "mlp_variant" | "ring_workgroups" | "ring_split" | "dw_workgroups",

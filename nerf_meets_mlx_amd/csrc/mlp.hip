@@ -1881,6 +1881,11 @@ struct SmallArgs {
   int64_t astride, zstride;
   // fused configs[4] query: rows are computed in the kernel from rays / depths / hash tables (16 levels x 2 features)
   const float* rays; const float* z; int n; const float* tables; uint32_t T; ResTab rt; float pos_scale, pos_offset;
+  // ray_major (inference of the fused query only): a 32-sample tile = ONE depth index of 32 ADJACENT RAYS instead of 32
+  // consecutive depths of one ray.  Neighbouring pixels' samples at the same depth are 0.0012 apart in the unit cube, so
+  // the 32 lanes of a gather instruction fall into the same or adjacent cells at every level below N_l ~ 800 (13 of 16),
+  // where 32 consecutive depths of one ray (0.021 apart) share cells only below N_l ~ 48.  Same values per sample.
+  int ray_major; int64_t B;
 };
 
 // B fragments of one sample straight from the hash tables and the view direction: lane (r, h) owns channels
@@ -1916,13 +1921,24 @@ __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
   constexpr int ST = 1;
   lds_load_stream(a.wf, a.bias);
   const int lane0 = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ntiles = (a.M + 31) >> 5;
+  const bool rmaj = FUSED && !STORE && a.ray_major;
+  const int64_t ntiles = rmaj ? ((a.B + 31) >> 5) * a.n : (a.M + 31) >> 5;
   LdsW ws;
   for (int64_t tile0 = (int64_t)blockIdx.x * 8 + wv; tile0 < ntiles; tile0 += (int64_t)gridDim.x * 8) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));        // fragment addresses are per-tile values: the 31 LDS reads are not hoisted (spills)
     const int r = lane & 31, h = lane >> 5;
-    int64_t m = tile0 * 32 + r; if (m >= a.M) m = a.M - 1;
+    int64_t m = tile0 * 32 + r;
+    bool valid = m < a.M;
+    if (rmaj) {                            // tile = (block of 32 rays, depth index): sample m = ray * n + depth
+      const int64_t rb = tile0 / a.n;
+      const int depth = (int)(tile0 - rb * a.n);
+      int64_t ray = rb * 32 + r;
+      valid = ray < a.B;
+      if (!valid) ray = a.B - 1;
+      m = ray * a.n + depth;
+    }
+    if (m >= a.M) m = a.M - 1;
     bf16x8 xin[ST][2], din[ST][1];
     if (FUSED) {
       ngp_row_frags(a, m, h, xin, din);
@@ -1966,10 +1982,9 @@ __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
       acc_init_bias(acc, ws, LN::BI_RGB, h);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws.frag(LN::F_RGB + ks, lane), hd[0][ks], acc, 0, 0, 0);
-      const int64_t mo = tile0 * 32 + r;
-      if (h == 0 && mo < a.M) {
+      if (h == 0 && valid) {
         float4 o; o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = alpha;
-        *reinterpret_cast<float4*>(a.out + mo * 4) = o;
+        *reinterpret_cast<float4*>(a.out + m * 4) = o;
       }
     }
 #undef SINK
@@ -2041,6 +2056,7 @@ static inline int64_t zstride16() { return (int64_t)L::Z_SLOTS * 64 + g_tile_pad
 static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: LDS ring, 8 waves x 32 samples, 32x32x16 MFMA,
                                 // 4: ring, 16x16x32 MFMA, 8 waves x 32 samples (inference only), 5: same, 4 waves x 64 samples
 static int g_ring_wgs = 0;       // persistent workgroups of the ring kernels; 0 = one per CU of the current device
+static int g_ngp_ray_major = 1;   // A/B knob: fused configs[4] inference query walks (32 rays x 1 depth) tiles (1) or (1 ray x 32 depths) tiles (0)
 static int g_ring_split = 1;     // training ring kernels: 1 = one 8-wave workgroup per CU (128 KiB ring), 2 = two 4-wave workgroups (64 KiB rings)
 // precision of a model = nerf_mlp_arch.precision (ABI 3): 16 (or 0) bf16 MFMA operands with fp32 accumulate, 32 the fp32
 // reference-precision kernels of mlp32.hip.  Nothing process-wide: two models of different precision can be packed,
@@ -2116,6 +2132,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "bwd_stage")) { g_bwd_stage = value; return NERF_OK; }
   if (!strcmp(key, "dw_job_mask")) { g_dw_job_mask = value; return NERF_OK; }
   if (!strcmp(key, "hash_combine_max_res")) { g_hash_combine_max_res = value > 0 ? value : 0; return NERF_OK; }
+  if (!strcmp(key, "ngp_ray_major")) { g_ngp_ray_major = value ? 1 : 0; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -2126,6 +2143,7 @@ extern "C" int nerf_get_option(const char* key) {
   if (!strcmp(key, "ring_split")) return g_ring_split;
   if (!strcmp(key, "dw_workgroups")) return g_dw_wgs;
   if (!strcmp(key, "hash_combine_max_res")) return g_hash_combine_max_res;
+  if (!strcmp(key, "ngp_ray_major")) return g_ngp_ray_major;
   return -1;
 }
 
@@ -2270,6 +2288,7 @@ static void small_args(SmallArgs& a, const void* packed) {
   a.x = nullptr; a.d_raw = nullptr; a.out = nullptr; a.d_x = nullptr; a.acts = nullptr; a.dz = nullptr; a.M = 0;
   a.astride = small_astride16(); a.zstride = small_zstride16();
   a.rays = nullptr; a.z = nullptr; a.n = 1; a.tables = nullptr; a.T = 0; a.pos_scale = 1.0f; a.pos_offset = 0.0f;
+  a.ray_major = 0; a.B = 0;
 }
 
 extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* packed, const float* x, int64_t M,
@@ -2515,7 +2534,9 @@ extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packe
   a.out = raw; a.acts = acts; a.M = M; a.rays = rays; a.z = z; a.n = n; a.tables = tables; a.T = 1u << log2_T;
   a.pos_scale = pos_scale; a.pos_offset = pos_offset;
   for (int l = 0; l < 32; ++l) a.rt.res[l] = l < L ? (float)resolutions_host[l] : 0.0f;
-  const int64_t nwg = ((M + 31) / 32 + 7) / 8;
+  a.B = B;
+  a.ray_major = (!acts && g_ngp_ray_major && B >= 32) ? 1 : 0;
+  const int64_t nwg = ((a.ray_major ? ((B + 31) / 32) * (int64_t)n : (M + 31) / 32) + 7) / 8;
   const dim3 g((unsigned)(nwg < 2048 ? nwg : 2048)), b(512);
   if (acts) hipLaunchKernelGGL((mlp_small_fwd_kernel<true, true>), g, b, LN::LDS_BYTES, as_stream(stream), a);
   else hipLaunchKernelGGL((mlp_small_fwd_kernel<false, true>), g, b, LN::LDS_BYTES, as_stream(stream), a);

@@ -444,3 +444,28 @@ def test_psnr_paired_ensemble_bf16_vs_reference_arithmetic():
         assert st["n"] == len(seeds)
         assert abs(st["mean_delta_db"]) <= 0.1 + st["ci95_half_width_db"], st
         assert st["mean_a"] > 11.5 and st["mean_b"] > 11.5                     # both arms are training (not the empty-volume 10.2 dB)
+
+
+def test_ngp_fused_inference_ray_major_tiles_are_bit_identical():
+    """The fused configs[4] inference query walks (32 adjacent rays x one depth) tiles by default (cache locality of the
+    hash gathers across neighbouring pixels); per sample nothing changes, so the output equals the (one ray x 32
+    depths) order bit for bit -- also with a ray count that is not a multiple of 32 and a tiny n."""
+    from nerf_meets_mlx_amd import _native, sampling
+    from nerf_meets_mlx_amd.rendering import ray
+    tr = _ngp(True)
+    for _ in range(3):
+        tr.train_step()
+    K = tr.K
+    L = _native.lib()
+    for B, n in ((100, 64), (33, 7), (31, 64), (4096, 64)):
+        idx = torch.arange(0, B, device=DEV, dtype=torch.int64)
+        rays = ray.gen_rays(tr.H, tr.W, K, tr.poses[0, :3, :4], 2.0, 6.0, idx % (tr.H * tr.W))
+        z = sampling.sample_coarse(rays, n)
+        outs = []
+        try:
+            for mode in (1, 0):
+                _native.check(L.nerf_set_option(b"ngp_ray_major", mode))
+                outs.append(tr.field.query(rays, z).clone())
+        finally:
+            _native.check(L.nerf_set_option(b"ngp_ray_major", 1))
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), (B, n)

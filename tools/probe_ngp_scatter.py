@@ -35,6 +35,20 @@ def timeit(fn, it=10):
 H = W = 800
 imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, 2, seed=0, device=dev)
 print("what,mode,levels,ms,atomics_G_per_s")
+# render chunk (32768 adjacent pixels x 64 samples) through the fused inference query: tile order A/B
+_tr = NGPTrainer(imgs, poses, K, N_rand=4096, n_depth_samples=64, seed=4, device=dev)
+for _ in range(20):
+    _tr.train_step()
+from nerf_meets_mlx_amd.rendering import ray as _ray
+_idx = torch.arange(32768, device=dev, dtype=torch.int64) + 200 * 800
+_rr = _ray.gen_rays(H, W, K, rposes[40][:3, :4], 2.0, 6.0, _idx)
+_z = sampling.sample_coarse(_rr, 64)
+for _mode in (0, 1):
+    N.check(N.lib().nerf_set_option(b"ngp_ray_major", _mode))
+    _t = timeit(lambda: _tr.field.query(_rr, _z))
+    print(f"fused_inference_query_32768x64,{'ray_major (32 rays x 1 depth)' if _mode else 'sample_major (1 ray x 32 depths)'},all,{_t:.4f},")
+N.check(N.lib().nerf_set_option(b"ngp_ray_major", 1))
+del _tr
 for det in (False, True):
     tr = NGPTrainer(imgs, poses, K, N_rand=4096, n_depth_samples=64, seed=4, device=dev, deterministic=det)
     for _ in range(20):
