@@ -352,11 +352,14 @@ def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev):
                    "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
         "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
         "loss_coarse": float(out["loss_coarse"]),
-        "roofline": {"bound": "hbm", "kernel": "hashgrid_bwd_kernel<2, 4> (table gradient scatter, float atomics)",
+        "roofline": {"bound": "hbm", "kernel": "hashgrid_bwd_combine_kernel<2> (levels 0-4) + hashgrid_bwd_kernel<2, 4> (table gradient scatter, "
+                               + ("int64 fixed-point integer atomics: deterministic" if tr.field.deterministic else "float atomics") + ")",
                      "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes": alg,
                      "ms_per_launch": k_ms, "samples_per_launch": M,
-                     "note": "atomic-rate bound: 256 float atomics per sample at ~20 G/s (device-scope atomics execute memory-side)"},
+                     "note": "atomic-request-rate bound (device-scope atomics execute memory-side, ~70 G/s on the collision-free fine levels; "
+                             "8-byte integer atomics cost what 4-byte float atomics cost); algorithmic bytes count a read-modify-write of 256 float32 "
+                             "table entries per sample"},
     }
     return line
 
