@@ -94,13 +94,14 @@ def main():
         parallel.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision, steps, warmup):
+    def measure(precision, steps, warmup, n_rand=None):
         """`steps` timed steps (train N_rand rays + render one chunk) of a fresh Trainer at `precision`, after `warmup`
         untimed ones, bracketed by barrier + synchronize; the dominant kernel (fused MLP forward of the render fine
         pass) and both phases are timed with events on the launch stream inside the timed region."""
         # seed 4: both networks start with sigma > 0 (a net whose raw sigma starts negative everywhere has an exactly
         # zero gradient under the reference's formulas and never trains -- DESIGN.md section 7)
-        tr = Trainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, N_importance=NI, seed=4, device=dev,
+        n_rand = args.n_rand if n_rand is None else n_rand
+        tr = Trainer(imgs, poses, K, N_rand=n_rand, n_depth_samples=64, N_importance=NI, seed=4, device=dev,
                      chunk=args.render_rays, precision=precision)
         ev, phase = [], {"train": [], "render": []}
 
@@ -150,7 +151,7 @@ def main():
         assert torch.isfinite(rgb).all() and torch.isfinite(out["loss_coarse"]).all()
         t_train = float(np.mean([a.elapsed_time(b) for a, b in phase["train"]])) * 1e-3
         t_render = float(np.mean([a.elapsed_time(b) for a, b in phase["render"]])) * 1e-3
-        return {"dt": dt, "steps": steps, "value": (args.n_rand + args.render_rays) * world * steps / dt,
+        return {"dt": dt, "steps": steps, "value": (n_rand + args.render_rays) * world * steps / dt, "n_rand": n_rand,
                 "ms_per_step": dt / steps * 1e3, "k_ms": float(np.mean([a.elapsed_time(b) for a, b in ev])),
                 "t_train": t_train, "t_render": t_render, "loss_coarse": float(out["loss_coarse"]),
                 "loss_fine": float(out.get("loss_fine", torch.zeros(1)))}
@@ -215,6 +216,14 @@ def main():
                              "roofline_frac": flop / (ms["k_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                              "train_rays_per_s": args.n_rand / ms["t_train"], "render_rays_per_s": args.render_rays / ms["t_render"],
                              "ratio_to_burst": ms["value"] / value, "dtype": "bf16"}
+        # ---- lego.txt's batch: the reference's configs/lego.txt trains with N_rand = 1024 (the headline uses the argparse
+        # default 4096, config_parser.py:17); same step, launch overheads weigh more
+        if args.n_rand != 1024:
+            ml = measure(16, args.steps, args.warmup, n_rand=1024)
+            line["lego_batch"] = {"n_rand_per_gpu": 1024, "value": ml["value"], "unit": "rays/s", "steps": ml["steps"],
+                                  "ms_per_step": ml["ms_per_step"], "train_rays_per_s": 1024 / ml["t_train"],
+                                  "render_rays_per_s": args.render_rays / ml["t_render"],
+                                  "train_mfma_frac": 3 * FLOP_PER_SAMPLE_FWD * spr * 1024 / ml["t_train"] / 1e12 / BF16_MFMA_PEAK_TFLOPS}
         # ---- fp32: the same step at the REFERENCE's arithmetic (models/NeRF.py:201-243 runs in MLX float32):
         # Trainer(precision=32) -> float32 operands on v_mfma_f32_32x32x2_f32, against the fp32 matrix peak
         m32 = measure(32, args.fp32_steps, 2)

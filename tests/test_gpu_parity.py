@@ -853,7 +853,7 @@ def test_bench_prints_one_contract_json_line(extra):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--n-rand", "256",
-           "--render-rays", "2048", "--hw", "64", "--no-cpu-baseline"] + extra
+           "--render-rays", "2048", "--hw", "64", "--no-cpu-baseline", "--sustain-seconds", "1", "--fp32-steps", "2"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -871,3 +871,11 @@ def test_bench_prints_one_contract_json_line(extra):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(d["value"] - (256 + 2048) * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    if "--config" not in extra:
+        # the legs the default N = 1 line carries beside the contract keys (round 3): the same step sustained, at the
+        # reference's arithmetic (fp32 models), at lego.txt's batch, and the configs[4] step
+        for leg in ("sustained", "fp32", "lego_batch", "ngp"):
+            assert leg in d and d[leg]["value"] > 0 and np.isfinite(d[leg]["value"]), leg
+        assert d["sustained"]["seconds"] >= 1.0 and 0.3 < d["sustained"]["ratio_to_burst"] < 3.0
+        assert d["fp32"]["dtype"] == "f32" and d["fp32"]["roofline"]["peak"] == 157.3 and d["fp32"]["value"] < d["value"]
+        assert d["lego_batch"]["n_rand_per_gpu"] == 1024 and "roofline" in d["ngp"]
