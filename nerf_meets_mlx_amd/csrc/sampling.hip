@@ -41,7 +41,7 @@ __global__ void add_noise_z_kernel(const float* __restrict__ z_in, const float* 
 
 // ---- importance sampling -------------------------------------------------------------------
 // LDS per wave: cdf[n+1], zmid[n+1], merged[n+N] (floats).
-constexpr int IS_CAP = 8;     // members kept per bucket of the counting sort below (iid uniforms: P(> 8 in a bucket) ~ 1e-6)
+constexpr int IS_CAP = 6;     // members kept per bucket of the counting sort below (iid uniforms: P(> 6 in a bucket) ~ 8e-5), uint16 each
 template <int CH>   // CH = ceil(n/64): consecutive bins handled by one lane in the scan
 __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict__ z, const float* __restrict__ w,
                                                          const float* __restrict__ u, int64_t B, int n, int N,
@@ -52,14 +52,14 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // per wave: cdf[n+1], zmid[n+1], merged[n+P] (floats), then the counting sort's u[P], cnt[P], base[P], members[P][IS_CAP]
   const int flt = (n + 1) * 2 + ((n + P + 3) & ~3);
-  const int per_wave = flt + P * (3 + IS_CAP);
+  const int per_wave = flt + P * 2 + (P * (1 + IS_CAP) + 1) / 2;      // in floats: u[P], cnt[P] (int), base[P] + members (uint16)
   float* s_cdf = smem + wv * per_wave;
   float* s_zmid = s_cdf + (n + 1);
   float* s_all = s_zmid + (n + 1);
   float* s_u = s_cdf + flt;
   int* s_cnt = reinterpret_cast<int*>(s_u + P);
-  int* s_base = s_cnt + P;
-  int* s_mem = s_base + P;
+  unsigned short* s_base = reinterpret_cast<unsigned short*>(s_cnt + P);
+  unsigned short* s_mem = s_base + P;
   for (int64_t ray = blockIdx.x * 4 + wv; ray < B; ray += (int64_t)gridDim.x * 4) {
     const float* zr = z + ray * n;
     const float* wr = w + ray * n;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
           k = k > P - 1 ? P - 1 : k;
           s_u[j] = uj;
           const int slot = atomicAdd(&s_cnt[k], 1);
-          if (slot < IS_CAP) s_mem[k * IS_CAP + slot] = j;
+          if (slot < IS_CAP) s_mem[k * IS_CAP + slot] = (unsigned short)j;
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
           float local = 0.0f;
           for (int c = 0; c < PB; ++c) { const int k = lane * PB + c; if (k < P) local += (float)s_cnt[k]; }
           float run = wave_scan_incl(local, lane) - local;
-          for (int c = 0; c < PB; ++c) { const int k = lane * PB + c; if (k < P) { s_base[k] = (int)run; run += (float)s_cnt[k]; } }
+          for (int c = 0; c < PB; ++c) { const int k = lane * PB + c; if (k < P) { s_base[k] = (unsigned short)(int)run; run += (float)s_cnt[k]; } }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
             int rank = 0;
             if (cnt <= IS_CAP) {
               for (int q = 0; q < cnt; ++q) {
-                const int m = s_mem[k * IS_CAP + q];
+                const int m = (int)s_mem[k * IS_CAP + q];
                 const float um = s_u[m];
                 rank += (int)((um < uj) || (um == uj && m < j) || (um != um && uj == uj) );
               }
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
               }
             }
             myz[c] = s_new[j];
-            mypos[c] = s_base[k] + rank;
+            mypos[c] = (int)s_base[k] + rank;
           }
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -288,7 +288,7 @@ extern "C" int nerf_importance_sample(const float* z, const float* weights, cons
   NERF_REQUIRE(z && weights && u, NERF_E_NULL, "nerf_importance_sample: z/weights/u is NULL");
   int P = 2;
   while (P < N) P <<= 1;                                  // bitonic sort width of the new depths
-  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3) + P * (3 + IS_CAP);
+  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3) + P * 2 + (P * (1 + IS_CAP) + 1) / 2;
   const size_t lds = (size_t)per_wave * 4 * sizeof(float);
   const int grid = (int)((B + 3) / 4 > 256 * 8 ? 256 * 8 : (B + 3) / 4);
   const int ch = (n + 63) / 64;
