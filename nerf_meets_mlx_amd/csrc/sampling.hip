@@ -41,7 +41,6 @@ __global__ void add_noise_z_kernel(const float* __restrict__ z_in, const float* 
 
 // ---- importance sampling -------------------------------------------------------------------
 // LDS per wave: cdf[n+1], zmid[n+1], merged[n+N] (floats).
-constexpr int IS_CAP = 6;     // members kept per bucket of the counting sort below (iid uniforms: P(> 6 in a bucket) ~ 8e-5), uint16 each
 template <int CH>   // CH = ceil(n/64): consecutive bins handled by one lane in the scan
 __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict__ z, const float* __restrict__ w,
                                                          const float* __restrict__ u, int64_t B, int n, int N,
@@ -50,16 +49,10 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
                                                          int64_t* __restrict__ inds_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // per wave: cdf[n+1], zmid[n+1], merged[n+P] (floats), then the counting sort's u[P], cnt[P], base[P], members[P][IS_CAP]
-  const int flt = (n + 1) * 2 + ((n + P + 3) & ~3);
-  const int per_wave = flt + P * 2 + (P * (1 + IS_CAP) + 1) / 2;      // in floats: u[P], cnt[P] (int), base[P] + members (uint16)
+  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3);
   float* s_cdf = smem + wv * per_wave;
   float* s_zmid = s_cdf + (n + 1);
   float* s_all = s_zmid + (n + 1);
-  float* s_u = s_cdf + flt;
-  int* s_cnt = reinterpret_cast<int*>(s_u + P);
-  unsigned short* s_base = reinterpret_cast<unsigned short*>(s_cnt + P);
-  unsigned short* s_mem = s_base + P;
   for (int64_t ray = blockIdx.x * 4 + wv; ray < B; ray += (int64_t)gridDim.x * 4) {
     const float* zr = z + ray * n;
     const float* wr = w + ray * n;
@@ -132,75 +125,7 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
       // LDS + two binary-search rank passes = O((n+N) log) instead of the O((n+N)^2) rank sort below.
       bool asc = true;
       for (int i = lane; i + 1 < n; i += WAVE) asc = asc && (s_all[i] <= s_all[i + 1]);
-      // ... and is the CDF non-decreasing (it is unless weights below -0.01 make a pdf negative)?  Then z_new is a
-      // monotone function of u (bin index, then t, then the lerp: every step is monotone in floating point too), so the
-      // new depths can be put in order by a COUNTING SORT ON u -- iid uniforms spread evenly over P buckets whatever the
-      // CDF looks like -- instead of a P-key bitonic network (28 dependent LDS exchange stages for P = 128: 58 of the
-      // kernel's 93 us per 32 768-ray chunk): bucket = floor(u P); LDS atomics count and collect the members of each
-      // bucket (arrival order is irrelevant: the rank inside a bucket is recomputed by (u, index)); a float DPP scan of the
-      // counts (exact: <= 512) gives the bucket bases; position = base + rank.  Buckets with more than IS_CAP members (a
-      // caller-supplied constant u, say) fall back to a scan of all N uniforms for their members only.
-      bool cdf_ok = true;
-      for (int i = lane; i < n; i += WAVE) cdf_ok = cdf_ok && (s_cdf[i] <= s_cdf[i + 1]);
-      if (__all(asc) && __all(cdf_ok)) {
-        for (int i = lane; i < P; i += WAVE) s_cnt[i] = 0;
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < N; j += WAVE) {
-          const float uj = u[ray * N + j];
-          int k = (uj >= 0.0f) ? (int)(uj * (float)P) : 0;           // NaN / negative -> bucket 0
-          k = k > P - 1 ? P - 1 : k;
-          s_u[j] = uj;
-          const int slot = atomicAdd(&s_cnt[k], 1);
-          if (slot < IS_CAP) s_mem[k * IS_CAP + slot] = (unsigned short)j;
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        {                                                            // exclusive prefix of the P counts: PB buckets per lane
-          const int PB = (P + WAVE - 1) / WAVE;
-          float local = 0.0f;
-          for (int c = 0; c < PB; ++c) { const int k = lane * PB + c; if (k < P) local += (float)s_cnt[k]; }
-          float run = wave_scan_incl(local, lane) - local;
-          for (int c = 0; c < PB; ++c) { const int k = lane * PB + c; if (k < P) { s_base[k] = (unsigned short)(int)run; run += (float)s_cnt[k]; } }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        float myz[8]; int mypos[8];                                  // N <= 512: at most 8 keys per lane
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int j = lane + c * WAVE;
-          myz[c] = 0.0f; mypos[c] = -1;
-          if (j < N) {
-            const float uj = s_u[j];
-            int k = (uj >= 0.0f) ? (int)(uj * (float)P) : 0;
-            k = k > P - 1 ? P - 1 : k;
-            const int cnt = s_cnt[k];
-            int rank = 0;
-            if (cnt <= IS_CAP) {
-              for (int q = 0; q < cnt; ++q) {
-                const int m = (int)s_mem[k * IS_CAP + q];
-                const float um = s_u[m];
-                rank += (int)((um < uj) || (um == uj && m < j) || (um != um && uj == uj) );
-              }
-            } else {
-              for (int m = 0; m < N; ++m) {
-                const float um = s_u[m];
-                int km = (um >= 0.0f) ? (int)(um * (float)P) : 0;
-                km = km > P - 1 ? P - 1 : km;
-                rank += (int)(km == k && ((um < uj) || (um == uj && m < j) || (um != um && uj == uj)));
-              }
-            }
-            myz[c] = s_new[j];
-            mypos[c] = (int)s_base[k] + rank;
-          }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();                              // every lane holds its depths: the list can be overwritten
-#pragma unroll
-        for (int c = 0; c < 8; ++c) if (mypos[c] >= 0) s_new[mypos[c]] = myz[c];
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-      } else if (__all(asc)) {
+      if (__all(asc)) {
         for (int i = N + lane; i < P; i += WAVE) s_new[i] = __builtin_inff();          // pad to a power of two
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -217,8 +142,6 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
             __builtin_amdgcn_wave_barrier();
           }
         }
-      }
-      if (__all(asc)) {
         // ties: coarse depths first.  rank(z_i) = i + #{new < z_i};  rank(new_j) = j + #{z <= new_j}
         for (int i = lane; i < n; i += WAVE) {
           const float v = s_all[i];
@@ -288,13 +211,12 @@ extern "C" int nerf_importance_sample(const float* z, const float* weights, cons
   NERF_REQUIRE(z && weights && u, NERF_E_NULL, "nerf_importance_sample: z/weights/u is NULL");
   int P = 2;
   while (P < N) P <<= 1;                                  // bitonic sort width of the new depths
-  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3) + P * 2 + (P * (1 + IS_CAP) + 1) / 2;
+  const int per_wave = (n + 1) * 2 + ((n + P + 3) & ~3);
   const size_t lds = (size_t)per_wave * 4 * sizeof(float);
   const int grid = (int)((B + 3) / 4 > 256 * 8 ? 256 * 8 : (B + 3) / 4);
   const int ch = (n + 63) / 64;
   auto st = as_stream(stream);
-#define LAUNCH(C) do { if (lds > 60 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(importance_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                       hipLaunchKernelGGL(importance_kernel<C>, dim3(grid), dim3(256), lds, st, z, weights, u, B, n, N, P, eps, z_new, z_merged, cdf, inds); } while (0)
+#define LAUNCH(C) hipLaunchKernelGGL(importance_kernel<C>, dim3(grid), dim3(256), lds, st, z, weights, u, B, n, N, P, eps, z_new, z_merged, cdf, inds)
   if (ch == 1) LAUNCH(1); else if (ch == 2) LAUNCH(2); else if (ch == 3) LAUNCH(3); else LAUNCH(4);
 #undef LAUNCH
   return check_launch("nerf_importance_sample");

@@ -474,10 +474,11 @@ def test_ngp_fused_inference_ray_major_tiles_are_bit_identical():
 @pytest.mark.parametrize("B,n,N,kind", [(50, 64, 128, "rand"), (7, 64, 128, "const"), (5, 64, 128, "linspace"), (9, 256, 512, "rand"),
                                         (4, 16, 5, "rand"), (3, 64, 128, "nan"), (6, 64, 128, "negcdf"), (4, 65, 100, "rand")])
 def test_importance_merge_counting_sort_paths(B, n, N, kind):
-    """The merge of the importance sampler orders the N new depths by a counting sort on u when the CDF is monotone (z_new
-    is then a monotone function of u) and by the bitonic network otherwise; every path must give sort(concat(z, z_new)):
-    iid uniforms, a constant u (every sample in one bucket: the overflow fallback), linspace incl. 1.0, NaN / negative u,
-    weights below -0.01 (non-monotone CDF: bitonic path), the largest supported sizes (110 KB of LDS), odd n / N."""
+    """The merge of the importance sampler (bitonic sort of the N new depths + rank merge with the ascending coarse list)
+    must give sort(concat(z, z_new)) for every kind of input: iid uniforms, a constant u, linspace incl. 1.0, NaN /
+    negative / > 1 uniforms, weights below -0.01 (non-monotone CDF), the largest supported sizes, odd n / N.
+    (Round 3 tried a rank sort -- slower, 151 vs 97 us per 32 768-ray chunk -- and a counting sort on u -- no faster:
+    the sort is not what bounds the kernel; both reverted, this test stays.)"""
     from nerf_meets_mlx_amd import sampling
     g = torch.Generator().manual_seed(B * 1000 + N)
     z = torch.sort(torch.rand(B, n, generator=g) * 4 + 2, -1).values
@@ -494,5 +495,5 @@ def test_importance_merge_counting_sort_paths(B, n, N, kind):
     z_new, z_m = sampling.importance_sample(z.to(DEV), w.to(DEV), N, u=u.to(DEV))
     want_new = O.sample_from_inverse_cdf(z, w[..., None], u)
     ok = torch.isfinite(want_new)
-    np.testing.assert_allclose(z_new.cpu().numpy()[ok.numpy()], want_new.numpy()[ok.numpy()], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(z_new.cpu().numpy()[ok.numpy()], want_new.numpy()[ok.numpy()], rtol=0, atol=5e-5)   # CDF in float64 here
     assert torch.equal(z_m.cpu(), torch.sort(torch.cat([z, z_new.cpu()], -1), -1).values)
