@@ -418,7 +418,7 @@ def test_psnr_paired_ensemble_bf16_vs_reference_arithmetic():
     8 seeds x 600 iterations, two HIP trainers per seed on identical batches / uniforms / initial weights:
       bf16 arm = the product path; fp32 arm = the reference's own arithmetic (fp32 MFMA kernels, 1e-4 per forward
       against the fp32 oracle).  Paired delta_s = PSNR_bf16 - PSNR_fp32 on held-out views (tools/psnr_ensemble.py; the
-      tracked 96-seed x 2500-iteration run of the same tool is profiles/r03_psnr_ensemble_*.jsonl).
+      tracked 170-seed x 2500-iteration run of the same tool is profiles/r03_psnr_ensemble_170seeds_*.jsonl).
     Asserted: (a) at 200 and 400 iterations, while most seeds are still close to one trajectory, the MEAN paired
     difference is within the target's 0.1 dB (measured here: -0.04 / -0.04 dB, single seeds up to 0.33 dB apart) and no
     seed is off by more than 0.6 dB; (b) at 600 iterations the mean paired difference is zero within its own 95 %

@@ -48,6 +48,21 @@ def main():
         alive = {sd for sd in done if sd in deads and not dead_any(deads[sd])}
         for st in summarise(rows, label="bf16_minus_fp32_alive_at_end_in_both_arms", only_seeds=alive):
             fp.write(json.dumps(st) + "\n")
+        # robust location of the heavy-tailed paired differences: median and 10 %-trimmed mean with bootstrap 95 % CIs
+        import numpy as np
+        rng = np.random.default_rng(0)
+        tm = lambda x: float(np.mean(np.sort(x)[int(0.1 * len(x)):len(x) - int(0.1 * len(x))]))
+        for it in sorted({r["iter"] for r in rows}):
+            d = np.array([r["delta_db"] for r in rows if r["iter"] == it and np.isfinite(r.get("delta_db", float("nan")))])
+            if len(d) < 8:
+                continue
+            bm = np.array([np.median(rng.choice(d, len(d))) for _ in range(4000)])
+            bt = np.array([tm(rng.choice(d, len(d))) for _ in range(4000)])
+            fp.write(json.dumps({"robust_iter": it, "n": int(len(d)), "median_delta_db": float(np.median(d)),
+                                 "median_ci95_bootstrap": [float(x) for x in np.percentile(bm, [2.5, 97.5])],
+                                 "trimmed10_mean_delta_db": tm(d), "trimmed10_ci95_bootstrap": [float(x) for x in np.percentile(bt, [2.5, 97.5])],
+                                 "n_within_0.5_db": int((np.abs(d) <= 0.5).sum()), "n_beyond_2_db": int((np.abs(d) > 2).sum()),
+                                 "min_delta_db": float(d.min()), "max_delta_db": float(d.max())}) + "\n")
         # when each arm first leaves / enters the dead-sigma state
         fp.write(json.dumps({"dead_sigma_summary": {
             arm: {f"seeds_ever_dead_{net}": [s for s in done if s in deads and deads[s][arm][net]["dead_iterations"] > 0] for net in ("coarse", "fine")}
