@@ -73,6 +73,7 @@ class HashNeRF:
         ng = max(1, min(int(level_groups), n_levels))
         self.level_groups = [(n_levels * i // ng, n_levels * (i + 1) // ng) for i in range(ng)]
         self.on_group_done = None           # NGPTrainer: called after each level group's scatter is enqueued (lo, hi)
+        self.on_mlp_grads = None            # NGPTrainer: called with the MLP gradient as soon as it is enqueued (before the scatters)
         self._pts, self._rz = None, None
         self.fused = os.environ.get("NERF_NGP_FUSED", "1") != "0"      # rows inside the forward kernel (default) or through HBM
         self.timing = None                  # bench.py: list that receives (start, end) events around the table scatter
@@ -132,6 +133,8 @@ class HashNeRF:
         last query(train=True).  accumulate=True adds into the gradient buffer as it stands (NGPTrainer: the Adam pass that
         consumed the previous gradient left it zeroed); the default clears it first."""
         grads, d_x = self.mlp.backward(d_raw, need_input_grad=True)
+        if self.on_mlp_grads is not None:
+            self.on_mlp_grads(grads)
         e = self.enc
         if not accumulate:
             e.grad.zero_()
@@ -184,23 +187,27 @@ class NGPTrainer(Trainer):
         z = sampling.sample_coarse(rays, self.n)
         raw = self.field.query(rays, z, train=True)
         loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, self.white_bkgd)
-        pending = []
+        pending, mlp_work = [], []
         if self.world > 1:
-            # all-reduce each level group's slice of the table gradient on the comm stream as soon as its scatter is
-            # enqueued: the transfer overlaps the next group's scatter, the MLP all-reduce and the MLP Adam
+            # Collectives of one process group run in issue order, so the small MLP gradient goes FIRST (it is complete
+            # before the scatters start), then each level group's slice of the table gradient as soon as its scatter is
+            # enqueued -- all on the comm stream, behind events: the transfers overlap the following groups' scatters,
+            # and the MLP Adam runs while the table slices are still on the wire.
             per_level = self.field.enc.hash_table_size * self.field.enc.n_features_per_level
             flat = self.field.table.grads
 
-            def group_done(lo, hi):
+            def on_comm(t):
                 ev = torch.cuda.Event()
                 ev.record()
                 self._comm.wait_event(ev)
                 with torch.cuda.stream(self._comm):
-                    pending.append(torch.distributed.all_reduce(flat[lo * per_level:hi * per_level], async_op=True))
-            self.field.on_group_done = group_done
+                    return torch.distributed.all_reduce(t, async_op=True)
+            self.field.on_mlp_grads = lambda g: mlp_work.append(on_comm(g))
+            self.field.on_group_done = lambda lo, hi: pending.append(on_comm(flat[lo * per_level:hi * per_level]))
         g_mlp, g_tab = self.field.backward(d_raw, accumulate=True)       # zeroed by the previous step's table Adam
-        self.field.on_group_done = None
-        parallel.allreduce_sum_(g_mlp)
+        self.field.on_group_done = self.field.on_mlp_grads = None
+        for w in mlp_work:
+            w.wait()
         self.opt.update(self.field.mlp, g_mlp, grad_scale=1.0 / self.world)
         for w in pending:
             w.wait()
