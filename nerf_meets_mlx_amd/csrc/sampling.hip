@@ -99,8 +99,9 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
     // per-lane binary search: inds = #{i : cdf[i] <= u}  (searchsorted side="right")
     for (int j = lane; j < N; j += WAVE) {
       const float uj = u[ray * N + j];
+      const bool unan = uj != uj;                                  // torch.searchsorted orders NaN after everything: inds = n + 1
       int lo = 0, hi = n + 1;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cdf[mid] <= uj) lo = mid + 1; else hi = mid; }
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (unan || s_cdf[mid] <= uj) lo = mid + 1; else hi = mid; }
       const int inds = lo;
       int below = inds - 1; below = below < 0 ? 0 : (below > n ? n : below);
       int above = inds;     above = above > n ? n : above;
