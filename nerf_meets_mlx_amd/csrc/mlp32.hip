@@ -144,6 +144,17 @@ __device__ __forceinline__ float* store_row(float* base, int64_t tile, int rows,
   return base + ((tile * rows + row) * 32 + col);
 }
 
+// The slab's [row][32 samples] image of a finished layer IS the layout of its rows in the activation / dZ store
+// ([tile][row][32 samples] float32): copy it with 16 bytes per lane (1 KiB per wave instruction) instead of one
+// 4-byte store per lane and element -- 4 x fewer store instructions in the training kernels.
+__device__ __forceinline__ void slab_to_store(const float* slab, float* dst, int rows) {
+  const int lane = threadIdx.x & 63;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's own slab writes
+  const float4* s4 = reinterpret_cast<const float4*>(slab);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int i = lane; i < rows * 8; i += 64) d4[i] = s4[i];
+}
+
 // out rows [32 nt + p(i) + 4 h] = act(W[nt-tile] . in + bias) for nt < NT, written to the wave's LDS slab (rows 0..32 NT)
 // and, when sink != nullptr, to rows sink_row0 + ... of the tile's activation store.
 template <int KT, bool RELU>
@@ -175,9 +186,9 @@ __device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fba
       const float v = RELU ? fmaxf(acc[i], 0.0f) : acc[i];
       const int row = 32 * nt + prow(i) + 4 * h;
       slab[row * 32 + col] = v;
-      if (sink) *store_row(sink, tile, A_ROWS, sink_row0 + row, col) = v;
     }
   }
+  if (sink) slab_to_store(slab, store_row(sink, tile, A_ROWS, sink_row0, 0), 32 * NT);
 }
 template <int KT>
 __device__ __forceinline__ void slab_to_regs(const float* slab, f32x16 (&dst)[KT], int col, int h) {
@@ -364,9 +375,9 @@ __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fba
       float v = acc[i];
       if (mask_row0 >= 0 && !(hm[i] > 0.0f)) v = 0.0f;
       slab[row * 32 + col] = v;
-      *store_row(dz, tile, Z_ROWS, zrow0 + row, col) = v;
     }
   }
+  slab_to_store(slab, store_row(dz, tile, Z_ROWS, zrow0, 0), 32 * KT);
 }
 
 __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
