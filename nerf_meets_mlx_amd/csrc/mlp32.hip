@@ -140,24 +140,6 @@ __device__ __forceinline__ void frag_issue_at(FragQ& f, const float* __restrict_
 __device__ __forceinline__ void frag_wait(FragQ& f) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.q[0]), "+v"(f.q[1]), "+v"(f.q[2]), "+v"(f.q[3]) : : "memory");
 }
-// the same wait when exactly ONE vector-memory operation (a deferred 1 KiB store, below) was issued after the fragment's loads
-__device__ __forceinline__ void frag_wait1(FragQ& f) {
-  asm volatile("s_waitcnt vmcnt(1)" : "+v"(f.q[0]), "+v"(f.q[1]), "+v"(f.q[2]), "+v"(f.q[3]) : : "memory");
-}
-// Deferred stores of the PREVIOUS layer's rows (still intact in the slab) during the next layer's MFMA steps: one 1 KiB
-// store per step, issued right behind that step's fragment loads, so that the step's wait can be vmcnt(1) and never has
-// to sit out a store's round trip.  (vmcnt counts loads and stores together, in issue order: a layer's 32 KiB of stores
-// issued in one burst at its end made the next layer's first fragment wait -- vmcnt(0) -- for all of them: +33 % on the
-// training forward, whatever the store width.)
-struct Deferred {
-  const float4* src; float4* dst; int left;       // 64-lane 16-byte pieces: `left` wave-stores of 1 KiB to go
-  __device__ __forceinline__ bool pending() const { return left > 0; }
-  __device__ __forceinline__ void one(int lane) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + lane);
-    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst + lane), "v"(v) : "memory");
-    src += 64; dst += 64; --left;
-  }
-};
 __device__ __forceinline__ float* store_row(float* base, int64_t tile, int rows, int row, int col) {
   return base + ((tile * rows + row) * 32 + col);
 }
@@ -177,14 +159,11 @@ __device__ __forceinline__ void slab_to_store(const float* slab, float* dst, int
 // and, when sink != nullptr, to rows sink_row0 + ... of the tile's activation store.
 template <int KT, bool RELU>
 __device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fbase, const float* __restrict__ bias, int NT,
-                                          const f32x16 (&in)[KT], float* slab, int col, int h, float* prev_dst, int prev_rows) {
+                                          const f32x16 (&in)[KT], float* slab, int col, int h, float* sink, int64_t tile,
+                                          int sink_row0) {
   // The weight fragments of a layer are consecutive in the stream: the NEXT fragment (4 KiB from L2) is requested before
   // the 16 MFMAs (1024 cycles) of the current one.  (The last prefetch of a layer reads the first fragment of whatever
-  // follows in the packed image: in bounds, unused.)  prev_dst != nullptr: the previous layer's rows (slab rows
-  // 0 .. prev_rows, not yet overwritten: tile nt of this layer overwrites rows 32 nt .. at its END, and by then
-  // (nt + 1) KT >= 4 (nt + 1) pieces of 8 rows have gone out) are stored one piece per step (struct Deferred).
-  const int lane = threadIdx.x & 63;
-  Deferred df{reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(prev_dst), prev_dst ? prev_rows / 8 : 0};
+  // follows in the packed image: in bounds, unused.)
   FragQ cur, nxt;
   frag_issue(cur, wl, fbase);
   frag_wait(cur);
@@ -194,14 +173,12 @@ __device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fba
     for (int i = 0; i < 16; ++i) acc[i] = bias[32 * nt + prow(i) + 4 * h];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      const bool st = df.pending();                                  // wave-uniform
       frag_issue(nxt, wl, fbase + nt * KT + kt + 1);
-      if (st) df.one(lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.q[i >> 2][i & 3], in[kt][i], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (st) frag_wait1(nxt); else frag_wait(nxt);
+      frag_wait(nxt);
       cur = nxt;
     }
 #pragma unroll
@@ -211,7 +188,7 @@ __device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fba
       slab[row * 32 + col] = v;
     }
   }
-  while (df.pending()) df.one(lane);                                 // (never taken for the shapes used: NT KT >= prev_rows / 8)
+  if (sink) slab_to_store(slab, store_row(sink, tile, A_ROWS, sink_row0, 0), 32 * NT);
 }
 template <int KT>
 __device__ __forceinline__ void slab_to_regs(const float* slab, f32x16 (&dst)[KT], int col, int h) {
@@ -290,8 +267,7 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
     pe[1] = embed_tile<1, 63, 10>(p, a.fpos, h);
     dpe[0] = embed_tile<0, 27, 4>(d, a.fdir, h);
   }
-  // rows of layer `row0` of this tile in the activation store (training only): each layer is stored by the NEXT one
-  auto rows_of = [&](int row0) -> float* { return STORE ? store_row(a.acts, tile, A_ROWS, row0, 0) : nullptr; };
+  float* sink = STORE ? a.acts : nullptr;
   if (STORE) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -301,10 +277,10 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
     for (int i = 0; i < 16; ++i) *store_row(a.acts, tile, A_ROWS, A_DPE + prow(i) + 4 * h, col) = dpe[0][i];
   }
   f32x16 hcur[8];
-  layer_fwd<2, true>(wl, F_L0, a.tail + T_B, 8, pe, slab, col, h, nullptr, 0);
+  layer_fwd<2, true>(wl, F_L0, a.tail + T_B, 8, pe, slab, col, h, sink, tile, A_H0);
   slab_to_regs<8>(slab, hcur, col, h);
-  for (int l = 1; l <= 4; ++l) {                                     // pos1..pos4 (each stores H_{l-1} while it computes)
-    layer_fwd<8, true>(wl, F_L1 + (l - 1) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * (l - 1)), 256);
+  for (int l = 1; l <= 4; ++l) {                                     // pos1..pos4
+    layer_fwd<8, true>(wl, F_L1 + (l - 1) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, sink, tile, A_H0 + 256 * l);
     slab_to_regs<8>(slab, hcur, col, h);
   }
   {                                                                  // pos5 on concat[input_pos, h]  (models/NeRF.py:224-225)
@@ -312,11 +288,11 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
     cat[0] = pe[0]; cat[1] = pe[1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) cat[2 + k] = hcur[k];
-    layer_fwd<10, true>(wl, F_L5, a.tail + T_B + 256 * 5, 8, cat, slab, col, h, rows_of(A_H0 + 256 * 4), 256);
+    layer_fwd<10, true>(wl, F_L5, a.tail + T_B + 256 * 5, 8, cat, slab, col, h, sink, tile, A_H0 + 256 * 5);
     slab_to_regs<8>(slab, hcur, col, h);
   }
   for (int l = 6; l <= 7; ++l) {
-    layer_fwd<8, true>(wl, F_L6 + (l - 6) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * (l - 1)), 256);
+    layer_fwd<8, true>(wl, F_L6 + (l - 6) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, sink, tile, A_H0 + 256 * l);
     slab_to_regs<8>(slab, hcur, col, h);
   }
   // alpha = Linear(256, 1)(h7): a dot product per sample on the vector ALU (models/NeRF.py:230)
@@ -328,16 +304,15 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
   alpha += __shfl_xor(alpha, 32, 64);
   alpha += a.tail[T_BA];
   // feature (no activation), then relu(Linear([feature, input_dir])), then rgb   (models/NeRF.py:231-238)
-  layer_fwd<8, false>(wl, F_FEAT, a.tail + T_BF, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * 7), 256);
+  layer_fwd<8, false>(wl, F_FEAT, a.tail + T_BF, 8, hcur, slab, col, h, sink, tile, A_FEAT);
   {
     f32x16 cat[9];
     slab_to_regs<8>(slab, hcur, col, h);
 #pragma unroll
     for (int k = 0; k < 8; ++k) cat[k] = hcur[k];
     cat[8] = dpe[0];
-    layer_fwd<9, true>(wl, F_DIR, a.tail + T_BD, 4, cat, slab, col, h, rows_of(A_FEAT), 256);
+    layer_fwd<9, true>(wl, F_DIR, a.tail + T_BD, 4, cat, slab, col, h, sink, tile, A_HD);
   }
-  if (STORE) slab_to_store(slab, rows_of(A_HD), 128);               // the last layer's rows: nothing follows to carry them
   f32x16 hd[4];
   slab_to_regs<4>(slab, hd, col, h);
   float rgb[3] = {0.0f, 0.0f, 0.0f};
@@ -368,12 +343,8 @@ struct BwdArgs32 {
 // mask_row0 >= 0: ReLU' from the stored activation rows mask_row0 + ... (H > 0); extra_w: rank-1 term w[row] * extra_s
 template <int NS>
 __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fbase, int KT, const f32x16 (&in)[NS],
-                                          float* slab, int col, int h, const float* __restrict__ acts, int64_t tile,
-                                          int mask_row0, const float* extra_w, float extra_s, float* prev_dst, int prev_rows) {
-  // prev_dst: rows of the PREVIOUS chain step (still in the slab) go out one 1 KiB piece per MFMA step (struct Deferred:
-  // k-tile kt of this step overwrites slab rows 32 kt .. at its end, by when (kt + 1) NS >= 4 (kt + 1) pieces are out)
-  const int lane = threadIdx.x & 63;
-  Deferred df{reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(prev_dst), prev_dst ? prev_rows / 8 : 0};
+                                          float* slab, int col, int h, const float* __restrict__ acts, float* dz,
+                                          int64_t tile, int mask_row0, int zrow0, const float* extra_w, float extra_s) {
   FragQ cur, nxt;
   frag_issue(cur, wl, fbase);
   frag_wait(cur);
@@ -390,14 +361,12 @@ __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fba
     }
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      const bool st = df.pending();                                        // wave-uniform
       frag_issue(nxt, wl, fbase + kt * NS + ns + 1);                       // prefetch: see layer_fwd
-      if (st) df.one(lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.q[i >> 2][i & 3], in[ns][i], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (st) frag_wait1(nxt); else frag_wait(nxt);
+      frag_wait(nxt);
       cur = nxt;
     }
 #pragma unroll
@@ -408,7 +377,7 @@ __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fba
       slab[row * 32 + col] = v;
     }
   }
-  while (df.pending()) df.one(lane);                                       // (never taken: KT NS >= prev_rows / 8)
+  slab_to_store(slab, store_row(dz, tile, Z_ROWS, zrow0, 0), 32 * KT);
 }
 
 __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
@@ -442,18 +411,15 @@ __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
       *store_row(a.dz, tile, Z_ROWS, Z_D + row, col) = v;
     }
   f32x16 zc[8];
-  auto zrows = [&](int row0) -> float* { return store_row(a.dz, tile, Z_ROWS, row0, 0); };
-  // every chain step leaves its rows in the slab; the NEXT step stores them while it computes, the last one at the end
-  layer_bwd<4>(wl, B_DIR, 8, zd, slab, col, h, a.acts, tile, -1, nullptr, 0.0f, nullptr, 0);                            // d feature
+  layer_bwd<4>(wl, B_DIR, 8, zd, slab, col, h, a.acts, a.dz, tile, -1, Z_F, nullptr, 0.0f);                    // d feature
   slab_to_regs<8>(slab, zc, col, h);
-  layer_bwd<8>(wl, B_FEAT, 8, zc, slab, col, h, a.acts, tile, A_H0 + 256 * 7, a.tail + T_WA, g.w, zrows(Z_F), 256);      // dZ7 (stores d feature)
+  layer_bwd<8>(wl, B_FEAT, 8, zc, slab, col, h, a.acts, a.dz, tile, A_H0 + 256 * 7, Z_L0 + 256 * 7, a.tail + T_WA, g.w);   // dZ7
   slab_to_regs<8>(slab, zc, col, h);
-  for (int l = 7; l >= 1; --l) {                                   // dZ_{l-1} = relu'(H_{l-1}) * (W_l^T dZ_l)   (stores dZ_l)
-    layer_bwd<8>(wl, B_POS + 64 * (7 - l), 8, zc, slab, col, h, a.acts, tile, A_H0 + 256 * (l - 1), nullptr, 0.0f,
-                 zrows(Z_L0 + 256 * l), 256);
+  for (int l = 7; l >= 1; --l) {                                   // dZ_{l-1} = relu'(H_{l-1}) * (W_l^T dZ_l)
+    layer_bwd<8>(wl, B_POS + 64 * (7 - l), 8, zc, slab, col, h, a.acts, a.dz, tile, A_H0 + 256 * (l - 1), Z_L0 + 256 * (l - 1),
+                 nullptr, 0.0f);
     slab_to_regs<8>(slab, zc, col, h);
   }
-  slab_to_store(slab, zrows(Z_L0), 256);                            // dZ_0
 }
 
 // ------------------------------------------------------------------------------------------ dW / db
