@@ -12,7 +12,7 @@ constexpr int F_FRAGS = 580, B_FRAGS = 544, FRAG_BYTES = 4096, TAIL_FLOATS = 313
 constexpr int64_t PACKED_BYTES = (int64_t)(F_FRAGS + B_FRAGS) * FRAG_BYTES + (int64_t)TAIL_FLOATS * 4;
 
 // training stores: per 32-sample tile, `rows` feature rows of 32 floats (feature-major inside the tile)
-constexpr int A_ROWS = 2528, Z_ROWS = 2496;
+constexpr int A_ROWS = 2592, Z_ROWS = 2496;
 inline int64_t tiles_of(int64_t M) { return (M + 31) / 32; }
 inline int64_t acts_bytes(int64_t M) { return tiles_of(M) * A_ROWS * 128; }
 inline int64_t dz_bytes(int64_t M) { return tiles_of(M) * Z_ROWS * 128; }

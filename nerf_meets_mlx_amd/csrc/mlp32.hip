@@ -22,16 +22,22 @@
 #include "common.h"
 #include "mlp_params.h"
 #include "mlp32.h"
+#include <type_traits>
+#include <utility>
 
 namespace nerf {
 namespace f32 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef NERF_F32_ABLATE
+#define NERF_F32_ABLATE 0
+#endif
 
 __host__ __device__ constexpr int prow(int i) { return (i & 3) + 8 * (i >> 2); }     // + 4 h
 
 // tail of the packed image (floats)
 constexpr int T_B = 0;              // pos biases, 256 l
+constexpr int BIAS_FLOATS = 2432;   // T_B .. T_BD + 128: the part of the tail the forward keeps in LDS
 constexpr int T_BF = 2048, T_BD = 2304, T_BA = 2432, T_BR = 2433, T_WA = 2440, T_WR = 2696;
 static_assert(T_WR + 384 <= TAIL_FLOATS, "tail too small");
 // forward stream fragment bases
@@ -42,8 +48,9 @@ constexpr int B_DIR = 0, B_FEAT = 32, B_POS = 96;          // pos7, 6, ..., 1 at
 static_assert(B_POS + 7 * 64 == B_FRAGS, "backward stream");
 // activation / dZ store rows
 constexpr int A_PE = 0, A_DPE = 64, A_H0 = 96, A_FEAT = 2144, A_HD = 2400;
+constexpr int A_MASK = 2528;        // ReLU sign bits of H0..H7: 8 rows (1 KiB) per layer, 16 bytes per lane (see relu_bits)
 constexpr int Z_L0 = 0, Z_F = 2048, Z_D = 2304, Z_A = 2432, Z_RGB = 2464;
-static_assert(A_HD + 128 == A_ROWS && Z_RGB + 32 == Z_ROWS, "store rows");
+static_assert(A_HD + 128 == A_MASK && A_MASK + 64 == A_ROWS && Z_RGB + 32 == Z_ROWS, "store rows");
 
 // ------------------------------------------------------------------------------------------ packing
 __device__ float fwd_src(const float* __restrict__ p, int f, int n32, int kk) {
@@ -155,40 +162,122 @@ __device__ __forceinline__ void slab_to_store(const float* slab, float* dst, int
   for (int i = lane; i < rows * 8; i += 64) d4[i] = s4[i];
 }
 
-// out rows [32 nt + p(i) + 4 h] = act(W[nt-tile] . in + bias) for nt < NT, written to the wave's LDS slab (rows 0..32 NT)
-// and, when sink != nullptr, to rows sink_row0 + ... of the tile's activation store.
-template <int KT, bool RELU>
-__device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fbase, const float* __restrict__ bias, int NT,
-                                          const f32x16 (&in)[KT], float* slab, int col, int h, float* sink, int64_t tile,
-                                          int sink_row0) {
-  // The weight fragments of a layer are consecutive in the stream: the NEXT fragment (4 KiB from L2) is requested before
-  // the 16 MFMAs (1024 cycles) of the current one.  (The last prefetch of a layer reads the first fragment of whatever
-  // follows in the packed image: in bounds, unused.)
-  FragQ cur, nxt;
-  frag_issue(cur, wl, fbase);
-  frag_wait(cur);
-  for (int nt = 0; nt < NT; ++nt) {
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// wait until at most N vector-memory operations are outstanding, N = the number of LOADS issued after this fragment's.
+// vmcnt counts loads and stores in one counter; loads return in issue order among themselves, stores complete out of order
+// with respect to loads.  While one of the fragment's loads is pending so are the N younger ones (count > N): the wait is
+// safe whatever the stores do -- counting stores among the "younger operations that may stay in flight" is NOT (measured: a
+// store that completes early lets such a wait pass with the fragment still in flight).  Pending stores do count against N,
+// so with the younger loads landed (they were issued 1024+ cycles earlier) up to N stores may still be on their way.
+template <int N>
+__device__ __forceinline__ void frag_wait_n(FragQ& f) {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f.q[0]), "+v"(f.q[1]), "+v"(f.q[2]), "+v"(f.q[3]) : "n"(N) : "memory");
+}
+// Deferred stores of the PREVIOUS layer's rows (still intact in the wave's slab) during the next layer's MFMA steps: one
+// 1 KiB piece (8 rows) per step.  The piece is read from LDS one step ahead, so the store issues without an LDS wait.
+struct Deferred {
+  const f32x4* src; f32x4* dst; int n;              // lane-offset pointers; n pieces in all
+  f32x4 piece;
+  __device__ __forceinline__ void init(const float* slab, float* to, int rows, int lane) {
+    src = reinterpret_cast<const f32x4*>(slab) + lane; dst = reinterpret_cast<f32x4*>(to) + lane;
+    n = __builtin_amdgcn_readfirstlane(to ? rows / 8 : 0);        // wave-uniform (every lane has the same `to`)
+#if NERF_F32_ABLATE == 1     // timing-only build (make ab AB_FLAGS=-DNERF_F32_ABLATE=1): no deferred stores; results are wrong
+    n = 0;
+#endif
+    if (n > 0) piece = *src;
+  }
+  __device__ __forceinline__ void store_and_fetch(int step) {        // step < n
+    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(piece) : "memory");
+    dst += 64; src += 64;
+    if (step + 1 < n) piece = *src;
+  }
+};
+
+// out rows [32 nt + p(i) + 4 h] = act(W[nt-tile] . in + bias) for nt < NT, written to the wave's LDS slab (rows 0..32 NT).
+//
+// Weight stream: the fragments of a layer are consecutive; S register sets (S divides KT, so the set of a fragment is the
+// compile-time kt % S) hold the current fragment and the D = S - 1 requested ahead of it: fragment f + D is requested at
+// the top of step f into the set step f - 1 has just consumed, and step f ends with a COUNTED wait for fragment f + 1
+// (frag_wait_n<4 (D - 1)>: the loads of the D - 1 fragments behind it may stay in flight).
+//
+// prev_dst != nullptr: the previous layer's rows (slab rows 0 .. prev_rows: tile nt of THIS layer overwrites rows 32 nt ..
+// at its end, and piece p = rows 8 p .. is read at step p - 1 <= 4 nt + 2 < (nt + 1) KT) go out one piece per step.  With
+// D = 3 a wait lets 8 operations stay outstanding, i.e. -- the prefetched loads having landed -- the stores of the last 8
+// steps; with one burst per layer, and with D = 1 (vmcnt(0) every step), every layer paid its stores' round trips: +33 %
+// on the training forward (both measured).
+template <int KT, bool RELU, int S>
+__device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fbase, const float* bias_lds, int NT,
+                                          const f32x16 (&in)[KT], float* slab, int col, int h, float* prev_dst, int prev_rows,
+                                          uint4* relu_bits = nullptr) {
+  static_assert(KT % S == 0 && S >= 2, "the set of fragment (nt, kt) must be kt % S");
+  static_assert(KT >= 4 || S == 2, "");
+  constexpr int D = S - 1;
+  const int lane = threadIdx.x & 63;
+  Deferred df;
+  df.init(slab, prev_dst, prev_rows, lane);
+  FragQ q[S];
+#pragma unroll
+  for (int d = 0; d < D; ++d) frag_issue(q[d], wl, fbase + d);
+  frag_wait_n<4 * (D - 1)>(q[0]);
+  const float4* b4 = reinterpret_cast<const float4*>(bias_lds + 4 * h);
+  float4 bn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bn[j] = b4[2 * j];
+  // relu_bits (the 8-tile layers H0..H7 of a training pass): bit 16 (nt & 1) + i of word nt >> 1 = (row 32 nt + p(i) + 4 h of this
+  // lane's sample is > 0), one uint4 per lane and layer: what the backward chain needs of H -- 1 KiB per layer and tile
+  // instead of reading back the 32 KiB of float32 rows.  Kept as a 128-bit shift register: each tile enters at the top.
+  unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  auto tile = [&](int nt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = bias[32 * nt + prow(i) + 4 * h];
+    for (int j = 0; j < 4; ++j) { acc[4 * j] = bn[j].x; acc[4 * j + 1] = bn[j].y; acc[4 * j + 2] = bn[j].z; acc[4 * j + 3] = bn[j].w; }
+    if (!LAST) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      frag_issue(nxt, wl, fbase + nt * KT + kt + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.q[i >> 2][i & 3], in[kt][i], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      frag_wait(nxt);
-      cur = nxt;
+      for (int j = 0; j < 4; ++j) bn[j] = b4[8 * (nt + 1) + 2 * j];          // the next tile's biases
     }
+    const int step0 = nt * KT;
+    static_for<KT>([&](auto kt_c) {
+      constexpr int kt = decltype(kt_c)::value;
+      const int step = step0 + kt;
+      const bool st = step < df.n;                                              // wave-uniform
+      // the step's first MFMA goes ahead of its loads and store: with one wave per SIMD nothing else covers their issue
+      // cycles (address arithmetic + five vector-memory instructions), under a 64-cycle MFMA they are free
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[kt % S].q[0][0], in[kt][0], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!LAST || kt + D < KT) frag_issue(q[(kt + D) % S], wl, fbase + step + D);
+      if (st) df.store_and_fetch(step);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 1; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[kt % S].q[i >> 2][i & 3], in[kt][i], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // fragment step + 1: loads younger than it = those of fragments step + 2 .. step + D (fewer at the layer's end)
+      constexpr int YL = LAST ? (KT - 2 - kt < D - 1 ? KT - 2 - kt : D - 1) : D - 1;
+      if (YL >= 0) frag_wait_n<4 * (YL < 0 ? 0 : YL)>(q[(kt + 1) % S]);
+    });
+    unsigned bits = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const float v = RELU ? fmaxf(acc[i], 0.0f) : acc[i];
       const int row = 32 * nt + prow(i) + 4 * h;
       slab[row * 32 + col] = v;
+      if (RELU) bits |= (v > 0.0f ? 1u : 0u) << i;
     }
-  }
-  if (sink) slab_to_store(slab, store_row(sink, tile, A_ROWS, sink_row0, 0), 32 * NT);
+    if (RELU && relu_bits) {
+      m0 = (m0 >> 16) | (m1 << 16); m1 = (m1 >> 16) | (m2 << 16); m2 = (m2 >> 16) | (m3 << 16); m3 = (m3 >> 16) | (bits << 16);
+    }
+  };
+  for (int nt = 0; nt < NT - 1; ++nt) tile(nt, std::false_type{});
+  tile(NT - 1, std::true_type{});
+  for (int step = NT * KT; step < df.n; ++step) df.store_and_fetch(step);      // (not taken for the shapes used: NT KT >= prev_rows / 8)
+  if (RELU && relu_bits) *relu_bits = make_uint4(m0, m1, m2, m3);              // (NT == 8 for every layer that passes relu_bits)
 }
 template <int KT>
 __device__ __forceinline__ void slab_to_regs(const float* slab, f32x16 (&dst)[KT], int col, int h) {
@@ -244,6 +333,11 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
   const int col = lane & 31, h = lane >> 5;
   const int64_t ntiles = (a.M + 31) >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  // the layer biases (tail floats 0 .. BIAS_FLOATS) behind the slabs: read per n-tile with ds_read (lgkmcnt), so that no
+  // compiler-counted global load -- whose wait would be vmcnt(0) -- sits between the counted fragment waits of a layer
+  float* bias_lds = slab_smem + 4 * 256 * 32;
+  for (int i = threadIdx.x; i < BIAS_FLOATS; i += 256) bias_lds[i] = a.tail[i];
+  __syncthreads();
   if (tile >= ntiles) return;
   float* slab = slab_smem + wv * (256 * 32);
   const float4* wl = a.wf + lane * 4;
@@ -267,7 +361,9 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
     pe[1] = embed_tile<1, 63, 10>(p, a.fpos, h);
     dpe[0] = embed_tile<0, 27, 4>(d, a.fdir, h);
   }
-  float* sink = STORE ? a.acts : nullptr;
+  // rows `row0` ... of this tile in the activation store (training only): each layer is stored by the NEXT one
+  auto rows_of = [&](int row0) -> float* { return STORE ? store_row(a.acts, tile, A_ROWS, row0, 0) : nullptr; };
+  auto bits_of = [&](int l) -> uint4* { return STORE ? reinterpret_cast<uint4*>(store_row(a.acts, tile, A_ROWS, A_MASK + 8 * l, 0)) + lane : nullptr; };
   if (STORE) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -277,10 +373,10 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
     for (int i = 0; i < 16; ++i) *store_row(a.acts, tile, A_ROWS, A_DPE + prow(i) + 4 * h, col) = dpe[0][i];
   }
   f32x16 hcur[8];
-  layer_fwd<2, true>(wl, F_L0, a.tail + T_B, 8, pe, slab, col, h, sink, tile, A_H0);
+  layer_fwd<2, true, 2>(wl, F_L0, bias_lds + T_B, 8, pe, slab, col, h, nullptr, 0, bits_of(0));
   slab_to_regs<8>(slab, hcur, col, h);
-  for (int l = 1; l <= 4; ++l) {                                     // pos1..pos4
-    layer_fwd<8, true>(wl, F_L1 + (l - 1) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, sink, tile, A_H0 + 256 * l);
+  for (int l = 1; l <= 4; ++l) {                                     // pos1..pos4 (each stores H_{l-1} while it computes)
+    layer_fwd<8, true, 4>(wl, F_L1 + (l - 1) * 64, bias_lds + T_B + 256 * l, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * (l - 1)), 256, bits_of(l));
     slab_to_regs<8>(slab, hcur, col, h);
   }
   {                                                                  // pos5 on concat[input_pos, h]  (models/NeRF.py:224-225)
@@ -288,11 +384,11 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
     cat[0] = pe[0]; cat[1] = pe[1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) cat[2 + k] = hcur[k];
-    layer_fwd<10, true>(wl, F_L5, a.tail + T_B + 256 * 5, 8, cat, slab, col, h, sink, tile, A_H0 + 256 * 5);
+    layer_fwd<10, true, 5>(wl, F_L5, bias_lds + T_B + 256 * 5, 8, cat, slab, col, h, rows_of(A_H0 + 256 * 4), 256, bits_of(5));
     slab_to_regs<8>(slab, hcur, col, h);
   }
   for (int l = 6; l <= 7; ++l) {
-    layer_fwd<8, true>(wl, F_L6 + (l - 6) * 64, a.tail + T_B + 256 * l, 8, hcur, slab, col, h, sink, tile, A_H0 + 256 * l);
+    layer_fwd<8, true, 4>(wl, F_L6 + (l - 6) * 64, bias_lds + T_B + 256 * l, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * (l - 1)), 256, bits_of(l));
     slab_to_regs<8>(slab, hcur, col, h);
   }
   // alpha = Linear(256, 1)(h7): a dot product per sample on the vector ALU (models/NeRF.py:230)
@@ -304,15 +400,16 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
   alpha += __shfl_xor(alpha, 32, 64);
   alpha += a.tail[T_BA];
   // feature (no activation), then relu(Linear([feature, input_dir])), then rgb   (models/NeRF.py:231-238)
-  layer_fwd<8, false>(wl, F_FEAT, a.tail + T_BF, 8, hcur, slab, col, h, sink, tile, A_FEAT);
+  layer_fwd<8, false, 4>(wl, F_FEAT, bias_lds + T_BF, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * 7), 256);
   {
     f32x16 cat[9];
     slab_to_regs<8>(slab, hcur, col, h);
 #pragma unroll
     for (int k = 0; k < 8; ++k) cat[k] = hcur[k];
     cat[8] = dpe[0];
-    layer_fwd<9, true>(wl, F_DIR, a.tail + T_BD, 4, cat, slab, col, h, sink, tile, A_HD);
+    layer_fwd<9, true, 3>(wl, F_DIR, bias_lds + T_BD, 4, cat, slab, col, h, rows_of(A_FEAT), 256);
   }
+  if (STORE) slab_to_store(slab, rows_of(A_HD), 128);               // the last layer's rows: nothing follows to carry them
   f32x16 hd[4];
   slab_to_regs<4>(slab, hd, col, h);
   float rgb[3] = {0.0f, 0.0f, 0.0f};
@@ -339,45 +436,62 @@ struct BwdArgs32 {
   float* dz;
 };
 
-// dZ rows [32 kt + p(i) + 4 h] = mask(W^T[kt-tile] . in (+ extra)) for kt < KT -> LDS slab + dz store rows zrow0 + ...
-// mask_row0 >= 0: ReLU' from the stored activation rows mask_row0 + ... (H > 0); extra_w: rank-1 term w[row] * extra_s
+// dZ rows [32 kt + p(i) + 4 h] = mask(W^T[kt-tile] . in (+ extra)) for kt < KT -> the wave's LDS slab.
+// relu_bits != nullptr: ReLU' from the sign bits the forward kept for that layer (layer_fwd; one 16-byte load per lane and
+// chain step, issued and waited for in the prologue: no global load sits among the deferred stores, where its wait would
+// drain them); extra_w (LDS): rank-1 term w[row] * extra_s.
+// Fragment ring and deferred stores of the PREVIOUS chain step's rows as in layer_fwd (S = 4 sets, D = 3 ahead; k-tile kt
+// overwrites slab rows 32 kt .. at its end, piece p is read at step p - 1 <= 4 kt + 2 < (kt + 1) NS).
 template <int NS>
 __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fbase, int KT, const f32x16 (&in)[NS],
-                                          float* slab, int col, int h, const float* __restrict__ acts, float* dz,
-                                          int64_t tile, int mask_row0, int zrow0, const float* extra_w, float extra_s) {
-  FragQ cur, nxt;
-  frag_issue(cur, wl, fbase);
-  frag_wait(cur);
-  for (int kt = 0; kt < KT; ++kt) {
+                                          float* slab, int col, int h, const uint4* relu_bits, const float* extra_w,
+                                          float extra_s, float* prev_dst, int prev_rows) {
+  constexpr int S = 4, D = S - 1;
+  static_assert(NS % S == 0, "the set of fragment (kt, ns) must be ns % S");
+  const int lane = threadIdx.x & 63;
+  uint4 mw = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+  if (relu_bits) mw = *relu_bits;
+  Deferred df;
+  df.init(slab, prev_dst, prev_rows, lane);
+  FragQ q[S];
+#pragma unroll
+  for (int d = 0; d < D; ++d) frag_issue(q[d], wl, fbase + d);
+  frag_wait_n<4 * (D - 1)>(q[0]);
+  asm volatile("" : "+v"(mw.x), "+v"(mw.y), "+v"(mw.z), "+v"(mw.w));          // the compiler's wait for the sign bits: here
+  unsigned m0 = mw.x, m1 = mw.y, m2 = mw.z, m3 = mw.w;
+  auto ktile = [&](int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = extra_w ? extra_w[32 * kt + prow(i) + 4 * h] * extra_s : 0.0f;
-    // the ReLU decisions of this k-tile (stored activations of the forward) are fetched BEFORE the MFMAs: with one wave per
-    // SIMD (128 KiB of LDS slabs per workgroup) nothing else hides a global-load latency, and the 128 MFMAs below take 4 us
-    float hm[16];
-    if (mask_row0 >= 0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) hm[i] = *store_row(const_cast<float*>(acts), tile, A_ROWS, mask_row0 + 32 * kt + prow(i) + 4 * h, col);
-    }
-#pragma unroll
-    for (int ns = 0; ns < NS; ++ns) {
-      frag_issue(nxt, wl, fbase + kt * NS + ns + 1);                       // prefetch: see layer_fwd
+    const int step0 = kt * NS;
+    static_for<NS>([&](auto ns_c) {
+      constexpr int ns = decltype(ns_c)::value;
+      const int step = step0 + ns;
+      const bool st = step < df.n;                                              // wave-uniform
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[ns % S].q[0][0], in[ns][0], acc, 0, 0, 0);       // see layer_fwd
+      __builtin_amdgcn_sched_barrier(0);
+      if (!LAST || ns + D < NS) frag_issue(q[(ns + D) % S], wl, fbase + step + D);
+      if (st) df.store_and_fetch(step);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.q[i >> 2][i & 3], in[ns][i], acc, 0, 0, 0);
+      for (int i = 1; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[ns % S].q[i >> 2][i & 3], in[ns][i], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      frag_wait(nxt);
-      cur = nxt;
-    }
+      constexpr int YL = LAST ? (NS - 2 - ns < D - 1 ? NS - 2 - ns : D - 1) : D - 1;     // see layer_fwd
+      if (YL >= 0) frag_wait_n<4 * (YL < 0 ? 0 : YL)>(q[(ns + 1) % S]);
+    });
+    const unsigned bits = m0;                                                   // this k-tile's 16 decisions: the low half
+    m0 = (m0 >> 16) | (m1 << 16); m1 = (m1 >> 16) | (m2 << 16); m2 = (m2 >> 16) | (m3 << 16); m3 >>= 16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = 32 * kt + prow(i) + 4 * h;
-      float v = acc[i];
-      if (mask_row0 >= 0 && !(hm[i] > 0.0f)) v = 0.0f;
-      slab[row * 32 + col] = v;
+      slab[row * 32 + col] = (bits >> i) & 1u ? acc[i] : 0.0f;
     }
-  }
-  slab_to_store(slab, store_row(dz, tile, Z_ROWS, zrow0, 0), 32 * KT);
+  };
+  for (int kt = 0; kt < KT - 1; ++kt) ktile(kt, std::false_type{});
+  ktile(KT - 1, std::true_type{});
+  for (int step = KT * NS; step < df.n; ++step) df.store_and_fetch(step);       // (not taken: KT NS >= prev_rows / 8)
 }
 
 __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
@@ -385,6 +499,9 @@ __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
   const int col = lane & 31, h = lane >> 5;
   const int64_t ntiles = (a.M + 31) >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  float* wa_lds = slab_smem + 4 * 256 * 32;               // the alpha head's weights (rank-1 term of dZ7): see bias_lds
+  wa_lds[threadIdx.x] = a.tail[T_WA + threadIdx.x];
+  __syncthreads();
   if (tile >= ntiles) return;
   float* slab = slab_smem + wv * (256 * 32);
   const float4* wl = a.wb + lane * 4;
@@ -411,15 +528,20 @@ __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
       *store_row(a.dz, tile, Z_ROWS, Z_D + row, col) = v;
     }
   f32x16 zc[8];
-  layer_bwd<4>(wl, B_DIR, 8, zd, slab, col, h, a.acts, a.dz, tile, -1, Z_F, nullptr, 0.0f);                    // d feature
+  auto zrows = [&](int row0) -> float* { return store_row(a.dz, tile, Z_ROWS, row0, 0); };
+  // every chain step leaves its rows in the slab; the NEXT step stores them while it computes, the last one at the end
+  auto bits_of = [&](int l) -> const uint4* {
+    return reinterpret_cast<const uint4*>(store_row(const_cast<float*>(a.acts), tile, A_ROWS, A_MASK + 8 * l, 0)) + lane;
+  };
+  layer_bwd<4>(wl, B_DIR, 8, zd, slab, col, h, nullptr, nullptr, 0.0f, nullptr, 0);                                         // d feature
   slab_to_regs<8>(slab, zc, col, h);
-  layer_bwd<8>(wl, B_FEAT, 8, zc, slab, col, h, a.acts, a.dz, tile, A_H0 + 256 * 7, Z_L0 + 256 * 7, a.tail + T_WA, g.w);   // dZ7
+  layer_bwd<8>(wl, B_FEAT, 8, zc, slab, col, h, bits_of(7), wa_lds, g.w, zrows(Z_F), 256);                                  // dZ7 (stores d feature)
   slab_to_regs<8>(slab, zc, col, h);
-  for (int l = 7; l >= 1; --l) {                                   // dZ_{l-1} = relu'(H_{l-1}) * (W_l^T dZ_l)
-    layer_bwd<8>(wl, B_POS + 64 * (7 - l), 8, zc, slab, col, h, a.acts, a.dz, tile, A_H0 + 256 * (l - 1), Z_L0 + 256 * (l - 1),
-                 nullptr, 0.0f);
+  for (int l = 7; l >= 1; --l) {                                   // dZ_{l-1} = relu'(H_{l-1}) * (W_l^T dZ_l)   (stores dZ_l)
+    layer_bwd<8>(wl, B_POS + 64 * (7 - l), 8, zc, slab, col, h, bits_of(l - 1), nullptr, 0.0f, zrows(Z_L0 + 256 * l), 256);
     slab_to_regs<8>(slab, zc, col, h);
   }
+  slab_to_store(slab, zrows(Z_L0), 256);                            // dZ_0
 }
 
 // ------------------------------------------------------------------------------------------ dW / db
@@ -562,14 +684,15 @@ static bool debug_slot(int kind, int layer, int* row0, int* width) {
 
 // ------------------------------------------------------------------------------------------ host entry points
 constexpr int SLAB_BYTES = 4 * 256 * 32 * 4;        // 128 KiB: one 32 KiB slab per wave
+constexpr int FWD_LDS_BYTES = SLAB_BYTES + BIAS_FLOATS * 4, BWD_LDS_BYTES = SLAB_BYTES + 256 * 4;
 
 template <class K>
-static void want_lds(K kernel) {
+static void want_lds(K kernel, int bytes = SLAB_BYTES) {
   static bool done[64] = {};
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
   if (!done[d]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done[d] = true;
   }
 }
@@ -595,11 +718,11 @@ int forward(const void* packed32, const float* x, const float* rays, const float
   const int64_t blocks = (tiles_of(M) + 3) / 4;
   NERF_REQUIRE(blocks < (1ll << 31), NERF_E_SHAPE, "mlp forward (fp32): M too large");
   if (acts) {
-    want_lds(mlp32_fwd_kernel<true>);
-    hipLaunchKernelGGL(mlp32_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), SLAB_BYTES, s, a);
+    want_lds(mlp32_fwd_kernel<true>, FWD_LDS_BYTES);
+    hipLaunchKernelGGL(mlp32_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
   } else {
-    want_lds(mlp32_fwd_kernel<false>);
-    hipLaunchKernelGGL(mlp32_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), SLAB_BYTES, s, a);
+    want_lds(mlp32_fwd_kernel<false>, FWD_LDS_BYTES);
+    hipLaunchKernelGGL(mlp32_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
   }
   return check_launch("mlp forward (fp32)");
 }
@@ -611,8 +734,8 @@ int backward(const void* packed32, const void* acts, const float* d_raw, int64_t
   b.acts = static_cast<const float*>(acts); b.d_raw = d_raw; b.M = M; b.dz = static_cast<float*>(dz);
   const int64_t ntiles = tiles_of(M), blocks = (ntiles + 3) / 4;
   NERF_REQUIRE(blocks < (1ll << 31), NERF_E_SHAPE, "mlp backward (fp32): M too large");
-  want_lds(mlp32_bwd_kernel);
-  hipLaunchKernelGGL(mlp32_bwd_kernel, dim3((unsigned)blocks), dim3(256), SLAB_BYTES, s, b);
+  want_lds(mlp32_bwd_kernel, BWD_LDS_BYTES);
+  hipLaunchKernelGGL(mlp32_bwd_kernel, dim3((unsigned)blocks), dim3(256), BWD_LDS_BYTES, s, b);
   int rc = check_launch("mlp backward chain (fp32)");
   if (rc) return rc;
   DwArgs32 d;

@@ -50,7 +50,7 @@ def test_host_argument_validation_without_gpu():
     assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 63, 27, 4, 1, 4, 0))) == bf16_image     # 0 = default = 16
     assert lib.nerf_mlp_packed_bytes(C.byref(arch32)) == bf16_image + fp32_image
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
-    assert lib.nerf_mlp_acts_bytes(C.byref(arch32), 65) == 3 * 2528 * 128         # fp32 stores: rows x 32 floats per tile
+    assert lib.nerf_mlp_acts_bytes(C.byref(arch32), 65) == 3 * 2592 * 128         # fp32 stores: rows x 32 floats per tile (2528 activation rows + 64 of ReLU sign bits)
     assert lib.nerf_mlp_dz_bytes(C.byref(arch32), 65) == 3 * 2496 * 128
     assert lib.nerf_get_option(b"mlp_precision") == -1 and lib.nerf_get_option(b"nonsense") == -1
     assert lib.nerf_set_option(b"mlp_precision", 32) == -3                        # gone: NERF_E_UNSUPPORTED, with a pointer to the arch
