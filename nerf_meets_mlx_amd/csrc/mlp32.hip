@@ -14,9 +14,12 @@
 //    finished 32 x 32 tile goes to a wave-private 32 KiB LDS slab and the whole layer is read back into registers
 //    before the next one.  No workgroup barriers: the four waves of a workgroup never share data.
 //  * weights stream from a packed float32 image in consumption order, one coalesced 4 KiB fragment (16 floats per
-//    lane) per 16 MFMAs, straight from L2 (1 024 MFMA cycles per fragment: no staging needed).
+//    lane) per 16 MFMAs, straight from L2 into a ring of S register sets, D = S - 1 fragments ahead (asm loads, counted
+//    waits: frag_wait_n).
 //  * training stores every layer's activation / dZ as float32 [tile][feature row][32 samples]; the dW kernel reads them
-//    as MFMA operands directly (samples are the K axis; a lane reads 16 consecutive samples of its feature row).
+//    as MFMA operands directly (samples are the K axis; a lane reads 16 consecutive samples of its feature row).  A
+//    layer's rows are stored by the NEXT layer, one 1 KiB piece per MFMA step (struct Deferred); the backward chain takes
+//    its ReLU decisions from sign bits the forward keeps (A_MASK), not from the stored rows.
 //  * encodings use sinf / cosf on the float32 product x * f -- the reference's sin(x * f), not the hardware
 //    revolution-sine of the bf16 path.
 #include "common.h"
