@@ -147,6 +147,17 @@ __device__ __forceinline__ void frag_issue_at(FragQ& f, const float* __restrict_
   asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.q[2]) : "v"(p) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.q[3]) : "v"(p) : "memory");
 }
+// the same loads into ACCUMULATION registers (gfx950: vector-memory loads can target AGPRs and MFMA reads A / B from either
+// file).  With more fragments in flight than the 256 VGPRs hold, hipcc parks the surplus in AGPRs -- with v_accvgpr_write
+// straight behind the asm load, i.e. BEFORE the data has arrived (it cannot know the load is asynchronous).  Sets that are
+// to live in AGPRs are therefore loaded there in the first place.  (tools/check_inflight_regs.py scans the ISA for any
+// read of a load's destination ahead of the wait that covers it.)
+__device__ __forceinline__ void frag_issue_at_acc(FragQ& f, const float* __restrict__ p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(f.q[0]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=a"(f.q[1]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=a"(f.q[2]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=a"(f.q[3]) : "v"(p) : "memory");
+}
 __device__ __forceinline__ void frag_wait(FragQ& f) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.q[0]), "+v"(f.q[1]), "+v"(f.q[2]), "+v"(f.q[3]) : : "memory");
 }
@@ -561,8 +572,12 @@ struct DwArgs32 {
   const float* acts; const float* dz; float* grads;
 };
 
-// one wave = one unit: a 64 x 64 block (2 x 2 MFMA tiles) of one job's dW over one slice of the sample tiles
-__global__ void __launch_bounds__(256, 2) mlp32_dw_kernel(DwArgs32 a) {
+// one wave = one unit: a 64 x 64 block (2 x 2 MFMA tiles) of one job's dW over one slice of the sample tiles.
+// ONE wave per SIMD (all 512 registers): the operands of a sample tile (two dZ and two H fragments, 64 registers) come
+// through a ring of four register sets, three tiles ahead -- 12 000 MFMA cycles between a request and its use.  (Two waves
+// per SIMD with one tile ahead, the first version, left the matrix pipe idle 29 % of the time: an HBM miss takes about as
+// long as the 4 096 cycles of one tile's 64 MFMAs.)  Only loads are in flight here, so the counted waits are exact.
+__global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int r32 = lane & 31, h = lane >> 5;
   const int unit = blockIdx.x * 4 + wv;
@@ -590,48 +605,69 @@ __global__ void __launch_bounds__(256, 2) mlp32_dw_kernel(DwArgs32 a) {
   float bsum[2] = {0.0f, 0.0f};
   const bool n1 = nt0 + 1 < jb.n_tiles, k1 = kt0 + 1 < jb.k_tiles;
   // lane (row r32, half h) reads samples 16 h .. 16 h + 15 of its feature row: MFMA step s pairs sample s (h = 0) with sample
-  // 16 + s (h = 1) in both operands.  The next tile's four fragments are requested before this tile's 64 MFMAs (4096 cycles)
-  // so that their latency is covered by arithmetic instead of by the other wave of the SIMD alone.
-  auto issue_tile = [&](int t, FragQ (&za)[2], FragQ (&hb)[2]) {
+  // 16 + s (h = 1) in both operands
+  const float* zrow[2]; const float* hrow[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int row = jb.zrow0 + 32 * (nt0 + ((r == 0 || n1) ? r : 0)) + r32;
-      frag_issue_at(za[r], a.dz + (((int64_t)t * Z_ROWS + row) * 32 + 16 * h));
-    }
+  for (int r = 0; r < 2; ++r) zrow[r] = a.dz + (((int64_t)jb.zrow0 + 32 * (nt0 + ((r == 0 || n1) ? r : 0)) + r32) * 32 + 16 * h);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int row = jb.arow0 + 32 * (kt0 + ((c == 0 || k1) ? c : 0)) + r32;
-      frag_issue_at(hb[c], a.acts + (((int64_t)t * A_ROWS + row) * 32 + 16 * h));
+  for (int c = 0; c < 2; ++c) hrow[c] = a.acts + (((int64_t)jb.arow0 + 32 * (kt0 + ((c == 0 || k1) ? c : 0)) + r32) * 32 + 16 * h);
+  constexpr int S = 4, D = S - 1;
+  FragQ ring[S][4];                                       // [set][dZ r = 0, 1 | H c = 0, 1]
+  // sets 0 and 1 live in VGPRs, sets 2 and 3 in AGPRs (with the 64 accumulators: 128 + 192 registers)
+  auto issue_tile = [&](int t, FragQ (&f)[4], auto acc_tag) {
+    constexpr bool ACC = decltype(acc_tag)::value;
+    const float* z0 = zrow[0] + (int64_t)t * (Z_ROWS * 32); const float* z1 = zrow[1] + (int64_t)t * (Z_ROWS * 32);
+    const float* h0 = hrow[0] + (int64_t)t * (A_ROWS * 32); const float* h1 = hrow[1] + (int64_t)t * (A_ROWS * 32);
+    if (ACC) { frag_issue_at_acc(f[0], z0); frag_issue_at_acc(f[1], z1); frag_issue_at_acc(f[2], h0); frag_issue_at_acc(f[3], h1); }
+    else { frag_issue_at(f[0], z0); frag_issue_at(f[1], z1); frag_issue_at(f[2], h0); frag_issue_at(f[3], h1); }
+  };
+  auto wait_tile = [&](FragQ (&f)[4], int younger_tiles, auto acc_tag) {   // 16 loads per tile; `younger_tiles` is wave-uniform
+    constexpr bool ACC = decltype(acc_tag)::value;
+    if (younger_tiles >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (younger_tiles == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (ACC) asm volatile("" : "+a"(f[k].q[0]), "+a"(f[k].q[1]), "+a"(f[k].q[2]), "+a"(f[k].q[3]));
+      else asm volatile("" : "+v"(f[k].q[0]), "+v"(f[k].q[1]), "+v"(f[k].q[2]), "+v"(f[k].q[3]));
     }
   };
-  // asm loads (frag_issue_at / frag_wait): the next tile's four fragments are in flight during this tile's 64 MFMAs
-  FragQ za[2], hb[2], zan[2], hbn[2];
-  if (t_lo < t_hi) {
-    issue_tile(t_lo, za, hb);
-    frag_wait(za[0]); frag_wait(za[1]); frag_wait(hb[0]); frag_wait(hb[1]);
-  }
-  for (int t = t_lo; t < t_hi; ++t) {
-    const bool more = t + 1 < t_hi;
-    if (more) issue_tile(t + 1, zan, hbn);
-    __builtin_amdgcn_sched_barrier(0);
+  const int nt_mine = t_hi - t_lo;
+  static_for<D>([&](auto d_c) {
+    constexpr int d = decltype(d_c)::value;
+    if (d < nt_mine) issue_tile(t_lo + d, ring[d], std::integral_constant<bool, (d >= 2)>{});
+  });
+  if (nt_mine > 0) wait_tile(ring[0], (nt_mine - 1 < D - 1 ? nt_mine - 1 : D - 1), std::false_type{});
+  for (int t0 = t_lo; t0 < t_hi; t0 += S) {
+    static_for<S>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      const int t = t0 + i;
+      if (t < t_hi) {                                                // wave-uniform
+        FragQ (&f)[4] = ring[i];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0].q[0][0], f[2].q[0][0], acc[0][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + D < t_hi) issue_tile(t + D, ring[(i + D) % S], std::integral_constant<bool, ((i + D) % S >= 2)>{});   // the set tile t - 1 used
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (kt0 == 0) {
+        for (int r = 0; r < 2; ++r) {
+          if (kt0 == 0) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) bsum[r] += za[r].q[s >> 2][s & 3];
+            for (int s = 0; s < 16; ++s) bsum[r] += f[r].q[s >> 2][s & 3];
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = (r == 0 && c == 0) ? 1 : 0; s < 16; ++s)
+              acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[r].q[s >> 2][s & 3], f[2 + c].q[s >> 2][s & 3], acc[r][c], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t_hi) {
+          const int left = t_hi - 2 - t;                                 // tiles behind t + 1 that exist
+          wait_tile(ring[(i + 1) % S], left < D - 1 ? left : D - 1, std::integral_constant<bool, ((i + 1) % S >= 2)>{});
+        }
       }
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[r].q[s >> 2][s & 3], hb[c].q[s >> 2][s & 3], acc[r][c], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) {
-      frag_wait(zan[0]); frag_wait(zan[1]); frag_wait(hbn[0]); frag_wait(hbn[1]);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) { za[r] = zan[r]; hb[r] = hbn[r]; }
-    }
+    });
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {

@@ -1,0 +1,61 @@
+"""The fp32 kernels load their operands with asm loads and wait for them with their own counted s_waitcnt: hipcc must
+not touch a destination register before that wait (it parks such registers in AGPRs right behind the load as soon as the
+256 VGPRs run out -- measured on a version of the dW kernel with four VGPR sets in flight).  This test compiles
+csrc/mlp32.hip to ISA and scans it (tools/check_inflight_regs.py); CPU only (hipcc cross-compiles)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_inflight_regs as chk                                   # noqa: E402
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def test_scanner_flags_a_read_ahead_of_the_wait_and_accepts_the_counted_form():
+    bad = """
+        global_load_dwordx4 v[4:7], v[0:1], off
+        global_load_dwordx4 v[8:11], v[0:1], off offset:16
+        v_accvgpr_write_b32 a3, v5
+        s_waitcnt vmcnt(0)
+    """.split("\n")
+    n, found = chk.scan(bad)
+    assert n == 2 and len(found) == 1 and "reads a pending register" in found[0][1]
+    good = """
+        global_load_dwordx4 v[4:7], v[0:1], off
+        global_load_dwordx4 a[8:11], v[0:1], off offset:16
+        s_waitcnt vmcnt(1)
+        v_mfma_f32_32x32x2_f32 a[16:31], v4, v12, a[16:31]
+        s_waitcnt vmcnt(0)
+        v_mfma_f32_32x32x2_f32 a[16:31], a8, v12, a[16:31]
+    """.split("\n")
+    assert chk.scan(good)[1] == []
+    late = """
+        global_load_dwordx4 v[4:7], v[0:1], off
+        global_load_dwordx4 a[8:11], v[0:1], off offset:16
+        s_waitcnt vmcnt(1)
+        v_mfma_f32_32x32x2_f32 a[16:31], a8, v12, a[16:31]
+    """.split("\n")
+    assert len(chk.scan(late)[1]) == 1
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_fp32_kernels_never_touch_a_register_ahead_of_its_wait(tmp_path):
+    out = str(tmp_path / "mlp32.s")
+    src = os.path.join(ROOT, "nerf_meets_mlx_amd", "csrc", "mlp32.hip")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
+                    "-o", out, src], check=True, timeout=900)
+    text = open(out).read()
+    seen = 0
+    for name, body in chk.kernels(text):
+        if not any(k in name for k in ("mlp32_fwd_kernel", "mlp32_bwd_kernel", "mlp32_dw_kernel")):
+            continue
+        seen += 1
+        n_loads, bad = chk.scan(body)
+        assert n_loads > 50, name
+        assert bad == [], (name, bad[:3])
+    assert seen == 4                                                  # forward (store / no store), chain, dW
