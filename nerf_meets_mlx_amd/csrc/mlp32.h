@@ -15,7 +15,9 @@ constexpr int64_t PACKED_BYTES = (int64_t)(F_FRAGS + B_FRAGS) * FRAG_BYTES + (in
 constexpr int A_ROWS = 2592, Z_ROWS = 2496;
 inline int64_t tiles_of(int64_t M) { return (M + 31) / 32; }
 inline int64_t acts_bytes(int64_t M) { return tiles_of(M) * A_ROWS * 128; }
-inline int64_t dz_bytes(int64_t M) { return tiles_of(M) * Z_ROWS * 128; }
+// dW: split-K partial blocks (64 x 64 floats + 64 bias sums per unit, at most DW32_MAX_UNITS units) behind the dZ rows
+constexpr int DW32_PART_FLOATS = 4096 + 64, DW32_MAX_UNITS = 2048;
+inline int64_t dz_bytes(int64_t M) { return tiles_of(M) * Z_ROWS * 128 + (int64_t)DW32_MAX_UNITS * DW32_PART_FLOATS * 4; }
 
 int pack(const float* params, void* packed32, hipStream_t s);
 // x != nullptr: embedded rows [M,90]; else rays [B,11] + z [B,n] with the encodings evaluated in the kernel

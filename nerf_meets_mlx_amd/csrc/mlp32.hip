@@ -568,8 +568,10 @@ constexpr int DW32_MAX_JOBS = 16;
 struct DwArgs32 {
   DwJob32 jobs[DW32_MAX_JOBS];
   int unit0[DW32_MAX_JOBS + 1];    // first unit of each job; unit = (block, split)
+  int blk0[DW32_MAX_JOBS + 1];     // first 64 x 64 block of each job (the reduce kernel's grid index)
   int njobs, splits, ntiles;
   const float* acts; const float* dz; float* grads;
+  float* part;                     // per-unit partial blocks: DW32_PART_FLOATS floats each (behind the dZ rows of the workspace)
 };
 
 // one wave = one unit: a 64 x 64 block (2 x 2 MFMA tiles) of one job's dW over one slice of the sample tiles.
@@ -669,24 +671,45 @@ __global__ void __launch_bounds__(256) mlp32_dw_kernel(DwArgs32 a) {
       }
     });
   }
+  // the unit's partial block goes to its own slot with plain coalesced stores (256 B per instruction); mlp32_dw_reduce_kernel
+  // adds the splits of a block in split order: no atomics, no memset, bit-reproducible gradients (as in the bf16 path)
+  float* mine = a.part + (int64_t)unit * DW32_PART_FLOATS;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    if (r == 1 && !n1) continue;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (c == 1 && !k1) continue;
-      const int colk = 32 * (kt0 + c) + r32;
-      if (colk >= jb.k_valid) continue;
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = 32 * (nt0 + r) + prow(i) + 4 * h;
-        if (n < jb.n_valid) atomicAdd(a.grads + jb.w_off + (int64_t)n * jb.ldw + jb.col0 + colk, acc[r][c][i]);
-      }
-    }
-    if (kt0 == 0 && jb.b_off >= 0) {
-      const float tot = bsum[r] + __shfl_xor(bsum[r], 32, 64);
+      for (int i = 0; i < 16; ++i) mine[((r * 2 + c) * 16 + i) * 64 + lane] = acc[r][c][i];
+    const float tot = bsum[r] + __shfl_xor(bsum[r], 32, 64);
+    if (h == 0) mine[4096 + 32 * r + r32] = tot;
+  }
+}
+
+// grid (job's 64 x 64 block, slice of its elements): sums the block's `splits` partials in split order and writes the gradient
+__global__ void __launch_bounds__(256) mlp32_dw_reduce_kernel(DwArgs32 a) {
+  int j = 0;
+  while ((int)blockIdx.x >= a.blk0[j + 1]) ++j;
+  const DwJob32 jb = a.jobs[j];
+  const int kb = (jb.k_tiles + 1) / 2;
+  const int nblocks = ((jb.n_tiles + 1) / 2) * kb;
+  const int block = blockIdx.x - a.blk0[j];
+  const int nt0 = 2 * (block / kb), kt0 = 2 * (block % kb);
+  const float* p0 = a.part + ((int64_t)a.unit0[j] + block) * DW32_PART_FLOATS;
+  const int64_t stride = (int64_t)nblocks * DW32_PART_FLOATS;                  // unit = unit0 + split * nblocks + block
+  for (int e = threadIdx.x + 256 * blockIdx.y; e < DW32_PART_FLOATS; e += 256 * gridDim.y) {
+    float sum = 0.0f;
+    for (int sp = 0; sp < a.splits; ++sp) sum += p0[sp * stride + e];
+    if (e < 4096) {
+      const int lane = e & 63, i = (e >> 6) & 15, c = (e >> 10) & 1, r = e >> 11;
+      const int r32 = lane & 31, h = lane >> 5;
+      if ((r == 1 && nt0 + 1 >= jb.n_tiles) || (c == 1 && kt0 + 1 >= jb.k_tiles)) continue;
+      const int colk = 32 * (kt0 + c) + r32, n = 32 * (nt0 + r) + prow(i) + 4 * h;
+      if (colk < jb.k_valid && n < jb.n_valid) a.grads[jb.w_off + (int64_t)n * jb.ldw + jb.col0 + colk] = sum;
+    } else {
+      const int r = (e - 4096) >> 5, r32 = (e - 4096) & 31;
+      if (r == 1 && nt0 + 1 >= jb.n_tiles) continue;
       const int n = 32 * (nt0 + r) + r32;
-      if (h == 0 && n < jb.n_valid) atomicAdd(a.grads + jb.b_off + n, tot);
+      if (kt0 == 0 && jb.b_off >= 0 && n < jb.n_valid) a.grads[jb.b_off + n] = sum;
     }
   }
 }
@@ -798,15 +821,21 @@ int backward(const void* packed32, const void* acts, const float* d_raw, int64_t
   int splits = 2048 / blocks_total;                      // about two waves per SIMD of a 256-CU device
   if (splits < 1) splits = 1;
   if (splits > ntiles) splits = (int)ntiles;
-  d.unit0[0] = 0;
-  for (int j = 0; j < nj; ++j)
-    d.unit0[j + 1] = d.unit0[j] + ((d.jobs[j].n_tiles + 1) / 2) * ((d.jobs[j].k_tiles + 1) / 2) * splits;
+  d.unit0[0] = 0; d.blk0[0] = 0;
+  for (int j = 0; j < nj; ++j) {
+    const int nb = ((d.jobs[j].n_tiles + 1) / 2) * ((d.jobs[j].k_tiles + 1) / 2);
+    d.unit0[j + 1] = d.unit0[j] + nb * splits;
+    d.blk0[j + 1] = d.blk0[j] + nb;
+  }
+  NERF_REQUIRE(d.unit0[nj] <= DW32_MAX_UNITS, NERF_E_SHAPE, "mlp dW (fp32): %d units", d.unit0[nj]);
   d.njobs = nj; d.splits = splits; d.ntiles = (int)ntiles;
   d.acts = b.acts; d.dz = b.dz; d.grads = grads;
-  hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * L::P_TOTAL, s);
-  if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward (fp32): memset: %s", hipGetErrorString(e));
+  d.part = reinterpret_cast<float*>(static_cast<char*>(dz) + ntiles * Z_ROWS * 128);     // dz_bytes() counts the slots
   hipLaunchKernelGGL(mlp32_dw_kernel, dim3((d.unit0[nj] + 3) / 4), dim3(256), 0, s, d);
-  return check_launch("mlp dW (fp32)");
+  rc = check_launch("mlp dW (fp32)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mlp32_dw_reduce_kernel, dim3(d.blk0[nj], 8), dim3(256), 0, s, d);       // every parameter is written: no memset
+  return check_launch("mlp dW reduce (fp32)");
 }
 
 int debug_width(int kind, int layer) {

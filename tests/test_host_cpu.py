@@ -51,7 +51,7 @@ def test_host_argument_validation_without_gpu():
     assert lib.nerf_mlp_packed_bytes(C.byref(arch32)) == bf16_image + fp32_image
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
     assert lib.nerf_mlp_acts_bytes(C.byref(arch32), 65) == 3 * 2592 * 128         # fp32 stores: rows x 32 floats per tile (2528 activation rows + 64 of ReLU sign bits)
-    assert lib.nerf_mlp_dz_bytes(C.byref(arch32), 65) == 3 * 2496 * 128
+    assert lib.nerf_mlp_dz_bytes(C.byref(arch32), 65) == 3 * 2496 * 128 + 2048 * (4096 + 64) * 4      # + split-K partial blocks of dW
     assert lib.nerf_get_option(b"mlp_precision") == -1 and lib.nerf_get_option(b"nonsense") == -1
     assert lib.nerf_set_option(b"mlp_precision", 32) == -3                        # gone: NERF_E_UNSUPPORTED, with a pointer to the arch
     assert b"nerf_mlp_arch.precision" in lib.nerf_last_error()
