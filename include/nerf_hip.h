@@ -35,7 +35,10 @@ extern "C" {
  * always size their buffers with these functions are unaffected; new entry points were only added.                  */
 /* 3 (round 3): `precision` became a field of nerf_mlp_arch (was the process-global option "mlp_precision"):
  * nerf_mlp_packed_bytes / _acts_bytes / _dz_bytes / _pack and every forward / backward read it from the arch they are
- * given.  The struct grew by one int at the end; a v2 caller must be recompiled.                                  */
+ * given.  The struct grew by one int at the end; a v2 caller must be recompiled.  (Later in round 3, no ABI change: for
+ * precision 32 nerf_mlp_acts_bytes counts 64 more rows per 32-sample tile -- the ReLU sign bits the backward chain reads
+ * instead of the float32 rows -- and nerf_mlp_dz_bytes 34 MB of split-K partial blocks, so that the fp32 weight gradient
+ * is a fixed-order sum like the bf16 one: bit-reproducible, no atomics.)                                           */
 #define NERF_ABI_VERSION 3
 
 #define NERF_OK 0
