@@ -10,6 +10,7 @@
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -526,3 +527,12 @@ def test_fp32_models_are_bit_reproducible():
             t.train_step()
     for k, ma in ts[0]._checkpoint_buffers().items():
         assert torch.equal(ma.params, ts[1]._checkpoint_buffers()[k].params), k
+
+
+def test_fp32_kernels_repeat_bit_for_bit_under_concurrent_load():
+    """tools/stress_fp32.py, short: 24 x (training forward, backward, inference forward) of an fp32 model at 1024 x 192
+    samples, each compared bit for bit with the first, bf16 kernels on a second stream every other iteration.  Guards
+    the counted waits of the asm-loaded weight / operand fragments (a wait that passes early = a few stale values)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_fp32
+    assert stress_fp32.run(iters=24, B=1024, n=192, dev=DEV, verbose=False) == 0
