@@ -35,11 +35,10 @@
 #ifndef NERF_ABLATE
 #define NERF_ABLATE 0
 #endif
-// 1 = count the fragment stores of the last three chunk intervals into the ring's vmcnt wait (measured: no gain in
-// the training forward, and the backward chain spills with it: 2.7 -> 5.0 ms).  Kept as a negative result, off.
-#ifndef NERF_EXACT_VMCNT
-#define NERF_EXACT_VMCNT 0
-#endif
+// (Round 1 had a switch NERF_EXACT_VMCNT that counted the fragment stores of the last three chunk intervals into the ring's
+// vmcnt wait: no gain in the training forward, spills in the backward chain -- and, as the fp32 kernels showed in round 3,
+// WRONG in principle: stores complete out of order with respect to loads, so a wait may only count younger LOADS
+// (mlp32.hip, frag_wait_n).  Removed.)
 // A/B switches (both default on): non-temporal DMA loads in the dW kernel / non-temporal fragment stores
 #ifndef NERF_NT_DW_LOADS
 #define NERF_NT_DW_LOADS 1
@@ -298,7 +297,6 @@ struct RingW {
   int ring_pos;                        // stage of the chunk the prefetch reads from
   int woff;                            // ring_pos * STAGE + 16 * lane
   bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
-  int st_cur, st_h1, st_h2;            // fragment stores issued in the current / previous two chunk intervals
 
   // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k
   __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
@@ -321,25 +319,14 @@ struct RingW {
     if (DPW == 8) {           // 4-wave workgroups: 8 DMAs per wave per chunk, two younger chunks stay in flight
       asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
-    // This chunk's DMAs were issued three boundaries ago.  Younger VMEM operations that may stay in flight: the 8
-    // DMAs of the next two chunks plus every activation / dZ store of the last three intervals (vmcnt retires in
-    // order and counts stores): waiting for fewer would stall the wave on HBM store latency at every boundary.
-    // Loads the compiler issues itself only make the true count larger, so this never under-waits.
-#if NERF_EXACT_VMCNT
-    const int allow = 8 + st_cur + st_h1 + st_h2;
-#else
-    const int allow = 8;
-#endif
-    if (allow >= 56)      asm volatile("s_waitcnt vmcnt(56) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (allow >= 48) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (allow >= 40) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (allow >= 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (allow >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (allow >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else                  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // This chunk's DMAs were issued three boundaries ago; the LOADS younger than them are the 8 DMAs of the next two
+    // chunks.  Loads (LDS-DMA included) return in issue order among themselves, so vmcnt(8) cannot pass while one of this
+    // chunk's DMAs is pending (then all 8 younger ones are too).  Stores share the counter but complete out of order with
+    // respect to loads: they may NOT be counted among the operations allowed to stay in flight (a store that completes
+    // early would let the wait pass too soon); pending stores simply count against the 8.  Loads the compiler issues
+    // itself only make the true count larger, so this never under-waits.
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    st_h2 = st_h1; st_h1 = st_cur; st_cur = 0;
 #endif
 #if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
     if (spread(c)) issue_one((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), 0);
@@ -360,12 +347,8 @@ struct RingW {
     for (int i = 0; i < RING_GROUP; ++i)
       nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % CHUNK) * 1024);
   }
-  __device__ __forceinline__ void note_stores(int k) { st_cur += k; }
-  // The counters restart at every pass (conservative: the first boundaries of a pass wait as if no store were in
-  // flight).  Inside the fully unrolled pass they are compile-time constants, so the `allow` ladder below folds to
-  // one s_waitcnt per boundary -- carried across passes it stayed a runtime 8-way branch that made hipcc spill.
+  __device__ __forceinline__ void note_stores(int) {}
   __device__ __forceinline__ void new_pass() {
-    st_cur = st_h1 = st_h2 = 0;
     // the ~1200 chunk/fragment source addresses are loop-invariant; hoisted, they no longer fit the SGPR file and
     // are parked in VGPR lanes (v_writelane / v_readlane per DMA).  Opaque base per pass: two s_add per DMA instead.
     asm volatile("" : "+s"(wsrc));
@@ -373,7 +356,6 @@ struct RingW {
   __device__ __forceinline__ void start(int lane) {
     ring_pos = STAGES - 1;
     woff = 0;
-    st_cur = st_h1 = st_h2 = 0;
 #pragma unroll
     for (int c = 0; c < STAGES - 1; ++c) issue(c, c);
     prefetch(0, lane);
