@@ -15,6 +15,9 @@ from psnr_ensemble import paired_stats, summarise                     # noqa: E4
 
 
 def main():
+    if len(sys.argv) < 3 or sys.argv[1].startswith("-"):
+        print(__doc__)
+        return 2
     out, ins = sys.argv[1], sys.argv[2:]
     rows, deads, cfg, seeds = [], {}, None, []
     for p in ins:
