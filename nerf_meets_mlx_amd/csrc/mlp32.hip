@@ -40,8 +40,8 @@ __host__ __device__ constexpr int prow(int i) { return (i & 3) + 8 * (i >> 2); }
 
 // tail of the packed image (floats)
 constexpr int T_B = 0;              // pos biases, 256 l
-constexpr int BIAS_FLOATS = 2432;   // T_B .. T_BD + 128: the part of the tail the forward keeps in LDS
 constexpr int T_BF = 2048, T_BD = 2304, T_BA = 2432, T_BR = 2433, T_WA = 2440, T_WR = 2696;
+constexpr int BIAS_FLOATS = T_WR + 384;   // the forward keeps the whole tail in LDS (biases, alpha and rgb heads)
 static_assert(T_WR + 384 <= TAIL_FLOATS, "tail too small");
 // forward stream fragment bases
 constexpr int F_L0 = 0, F_L1 = 16, F_L5 = 272, F_L6 = 352, F_FEAT = 480, F_DIR = 544;
@@ -410,9 +410,9 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) alpha += a.tail[T_WA + 32 * kt + prow(i) + 4 * h] * hcur[kt][i];
+    for (int i = 0; i < 16; ++i) alpha += bias_lds[T_WA + 32 * kt + prow(i) + 4 * h] * hcur[kt][i];
   alpha += __shfl_xor(alpha, 32, 64);
-  alpha += a.tail[T_BA];
+  alpha += bias_lds[T_BA];
   // feature (no activation), then relu(Linear([feature, input_dir])), then rgb   (models/NeRF.py:231-238)
   layer_fwd<8, false, 4>(wl, F_FEAT, bias_lds + T_BF, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * 7), 256);
   {
@@ -432,9 +432,9 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) rgb[c] += a.tail[T_WR + c * 128 + 32 * kt + prow(i) + 4 * h] * hd[kt][i];
+      for (int i = 0; i < 16; ++i) rgb[c] += bias_lds[T_WR + c * 128 + 32 * kt + prow(i) + 4 * h] * hd[kt][i];
     rgb[c] += __shfl_xor(rgb[c], 32, 64);
-    rgb[c] += a.tail[T_BR + c];
+    rgb[c] += bias_lds[T_BR + c];
   }
   const int64_t mo = tile * 32 + col;
   if (h == 0 && mo < a.M) {
@@ -514,7 +514,9 @@ __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
   const int64_t ntiles = (a.M + 31) >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
   float* wa_lds = slab_smem + 4 * 256 * 32;               // the alpha head's weights (rank-1 term of dZ7): see bias_lds
+  float* wr_lds = wa_lds + 256;                           // the rgb head's weights [3][128]
   wa_lds[threadIdx.x] = a.tail[T_WA + threadIdx.x];
+  for (int i = threadIdx.x; i < 384; i += 256) wr_lds[i] = a.tail[T_WR + i];
   __syncthreads();
   if (tile >= ntiles) return;
   float* slab = slab_smem + wv * (256 * 32);
@@ -529,18 +531,28 @@ __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
     *store_row(a.dz, tile, Z_ROWS, Z_RGB + row, col) = row == 0 ? g.x : row == 1 ? g.y : row == 2 ? g.z : 0.0f;
     *store_row(a.dz, tile, Z_ROWS, Z_A + row, col) = row == 0 ? g.w : 0.0f;
   }
-  // d dir0 pre-activation = relu'(HD) * (Wr^T d rgb): 3 terms per unit, vector ALU
+  // d dir0 pre-activation = relu'(HD) * (Wr^T d rgb): 3 terms per unit, vector ALU.  All 64 HD loads first, the stores
+  // after them, the weights from LDS: written as one loop (load, use, store per element, weights from global memory) the
+  // stores -- which may alias the loads for all hipcc knows -- kept every element's loads behind the previous element's
+  // store: 64 serialized L2 round trips, 40-50 us of the 330 a tile takes.
   f32x16 zd[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      zd[kt][i] = *store_row(const_cast<float*>(a.acts), tile, A_ROWS, A_HD + 32 * kt + prow(i) + 4 * h, col);
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = 32 * kt + prow(i) + 4 * h;
-      float v = a.tail[T_WR + row] * g.x + a.tail[T_WR + 128 + row] * g.y + a.tail[T_WR + 256 + row] * g.z;
-      if (!(*store_row(const_cast<float*>(a.acts), tile, A_ROWS, A_HD + row, col) > 0.0f)) v = 0.0f;
-      zd[kt][i] = v;
-      *store_row(a.dz, tile, Z_ROWS, Z_D + row, col) = v;
+      const float v = wr_lds[row] * g.x + wr_lds[128 + row] * g.y + wr_lds[256 + row] * g.z;
+      zd[kt][i] = zd[kt][i] > 0.0f ? v : 0.0f;
     }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *store_row(a.dz, tile, Z_ROWS, Z_D + 32 * kt + prow(i) + 4 * h, col) = zd[kt][i];
   f32x16 zc[8];
   auto zrows = [&](int row0) -> float* { return store_row(a.dz, tile, Z_ROWS, row0, 0); };
   // every chain step leaves its rows in the slab; the NEXT step stores them while it computes, the last one at the end
@@ -746,7 +758,7 @@ static bool debug_slot(int kind, int layer, int* row0, int* width) {
 
 // ------------------------------------------------------------------------------------------ host entry points
 constexpr int SLAB_BYTES = 4 * 256 * 32 * 4;        // 128 KiB: one 32 KiB slab per wave
-constexpr int FWD_LDS_BYTES = SLAB_BYTES + BIAS_FLOATS * 4, BWD_LDS_BYTES = SLAB_BYTES + 256 * 4;
+constexpr int FWD_LDS_BYTES = SLAB_BYTES + BIAS_FLOATS * 4, BWD_LDS_BYTES = SLAB_BYTES + (256 + 384) * 4;
 
 template <class K>
 static void want_lds(K kernel, int bytes = SLAB_BYTES) {
