@@ -118,20 +118,13 @@ __global__ void __launch_bounds__(256) pack32_kernel(const float* __restrict__ p
 // ------------------------------------------------------------------------------------------ one layer
 extern __shared__ __attribute__((aligned(16))) float slab_smem[];      // 4 waves x 256 rows x 32 floats
 
-struct Frag16 { float w[16]; };
-__device__ __forceinline__ Frag16 load_frag(const float4* __restrict__ lane_base, int f) {
-  const float4* fp = lane_base + (int64_t)f * 256;
-  Frag16 r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const float4 v = fp[j]; r.w[4 * j] = v.x; r.w[4 * j + 1] = v.y; r.w[4 * j + 2] = v.z; r.w[4 * j + 3] = v.w; }
-  return r;
-}
-// The same fragment as four 128-bit registers loaded by INLINE-ASM global loads, for the weight stream of the chain kernels.
+// A fragment (16 floats per lane) as four 128-bit registers loaded by INLINE-ASM global loads: the weight stream of the chain
+// kernels and the operand tiles of the dW kernel.
 // hipcc's scheduler, at 250+ live registers, sinks ordinary loads to just before their first use (load; s_waitcnt vmcnt(0);
 // 4 MFMAs; load; ... -- every L2 round trip exposed, one wave per SIMD, nothing else to issue): measured 40-60 % of the
-// fp32 matrix peak.  With asm loads the issue point is ours: the NEXT fragment is requested before the 16 MFMAs (1024
-// cycles) of the current one, and frag_wait -- the only place its registers become visible to the compiler ("+v") -- sits
-// behind them.  s_waitcnt vmcnt(0) also drains whatever the compiler itself has in flight: always safe, never too early.
+// fp32 matrix peak.  With asm loads the issue point is ours: fragments are requested D steps (of 16 MFMAs = 1024 cycles) ahead
+// and the counted wait (frag_wait_n) -- the only place their registers become visible to the compiler ("+v") -- sits behind
+// the MFMAs of the step before their use.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct FragQ { f32x4 q[4]; };
 __device__ __forceinline__ void frag_issue(FragQ& f, const float4* __restrict__ lane_base, int frag) {
@@ -157,9 +150,6 @@ __device__ __forceinline__ void frag_issue_at_acc(FragQ& f, const float* __restr
   asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=a"(f.q[1]) : "v"(p) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=a"(f.q[2]) : "v"(p) : "memory");
   asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=a"(f.q[3]) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void frag_wait(FragQ& f) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.q[0]), "+v"(f.q[1]), "+v"(f.q[2]), "+v"(f.q[3]) : : "memory");
 }
 __device__ __forceinline__ float* store_row(float* base, int64_t tile, int rows, int row, int col) {
   return base + ((tile * rows + row) * 32 + col);
