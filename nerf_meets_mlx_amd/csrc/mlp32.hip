@@ -314,8 +314,10 @@ __device__ __forceinline__ float embed_pair(const float (&v)[3], const float (&f
   const float xa = v[a.dim], xb = v[b.dim];
   const float arg = h ? xb * fr[b.band] : xa * fr[a.band];        // x * freq as one float32 product, like the reference
   float sv = 0.0f, cv = 0.0f;
-  if (a.kind == 1 || b.kind == 1) sv = sinf(arg);
-  if (a.kind == 2 || b.kind == 2) cv = cosf(arg);
+  constexpr bool need_s = a.kind == 1 || b.kind == 1, need_c = a.kind == 2 || b.kind == 2;
+  if (need_s && need_c) sincosf(arg, &sv, &cv);                    // one argument reduction for the two lane halves
+  else if (need_s) sv = sinf(arg);
+  else if (need_c) cv = cosf(arg);
   const float va = a.kind == 0 ? xa : a.kind == 1 ? sv : a.kind == 2 ? cv : 0.0f;
   const float vb = b.kind == 0 ? xb : b.kind == 1 ? sv : b.kind == 2 ? cv : 0.0f;
   return h ? vb : va;
