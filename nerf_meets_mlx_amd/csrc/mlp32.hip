@@ -752,15 +752,19 @@ static bool debug_slot(int kind, int layer, int* row0, int* width) {
 constexpr int SLAB_BYTES = 4 * 256 * 32 * 4;        // 128 KiB: one 32 KiB slab per wave
 constexpr int FWD_LDS_BYTES = SLAB_BYTES + BIAS_FLOATS * 4, BWD_LDS_BYTES = SLAB_BYTES + (256 + 384) * 4;
 
+// opt in to more than 64 KiB of dynamic LDS, once per (kernel, device).  Keyed by the kernel's ADDRESS: the two forward
+// instantiations have the same function type, so a per-type flag (the first version) served only whichever ran first.
 template <class K>
 static void want_lds(K kernel, int bytes = SLAB_BYTES) {
-  static bool done[64] = {};
+  static const void* seen[8][64] = {};
+  const void* fn = reinterpret_cast<const void*>(kernel);
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
-  if (!done[d]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    done[d] = true;
+  for (int i = 0; i < 8; ++i) {
+    if (seen[i][d] == fn) return;
+    if (seen[i][d] == nullptr) { seen[i][d] = fn; break; }
   }
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 int pack(const float* params, void* packed32, hipStream_t s) {
