@@ -47,8 +47,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sustained / fp32 / ngp legs of the default N=1 line")
     ap.add_argument("--sustain-seconds", type=float, default=10.0, help="length of the sustained bf16 leg")
-    ap.add_argument("--fp32-steps", type=int, default=8, help="timed steps of the fp32 (reference arithmetic) leg")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="time box of each cpu_baseline leg")
+    ap.add_argument("--fp32-steps", type=int, default=20, help="timed steps of the fp32 (reference arithmetic) leg")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="time box of the cpu_baseline render leg (the training leg runs "
+                    "its 20 steps of SURVEY 8(d) whatever they take, capped at --cpu-train-cap seconds)")
+    ap.add_argument("--cpu-train-cap", type=float, default=600.0, help="safety cap of the cpu_baseline training leg")
     ap.add_argument("--mlp-variant", type=int, default=0)
     ap.add_argument("--n-importance", type=int, default=128, help="0 = coarse-only (BASELINE configs[1] with --hw 400)")
     ap.add_argument("--config", choices=["nerf", "ngp"], default="nerf",
@@ -104,6 +106,7 @@ def main():
         tr = Trainer(imgs, poses, K, N_rand=n_rand, n_depth_samples=64, N_importance=NI, seed=4, device=dev,
                      chunk=args.render_rays, precision=precision)
         ev, phase = [], {"train": [], "render": []}
+        parallel.comm_timing = [] if world > 1 else None        # (start, end) events around every gradient all-reduce
 
         def timed_fine_query(r, zf):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -138,23 +141,54 @@ def main():
         for _ in range(warmup):
             step()
         ev.clear(); phase["train"].clear(); phase["render"].clear()
+        if parallel.comm_timing is not None:
+            parallel.comm_timing.clear()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             out, rgb = step()
         barrier()
         dt = time.perf_counter() - t0
+        comm_ms = None
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            cm = parallel.comm_timing
+            parallel.comm_timing = None                          # the two reductions below are not part of the step
+            # collective time per step on this rank (events on the stream the collectives are issued on; includes waiting
+            # for the slowest rank) -> MAX over ranks like the step time
+            c = torch.tensor([sum(a.elapsed_time(b) for a, b in cm) / steps], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt = float(t[0])
+            torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.MAX)
+            dt, comm_ms = float(t[0]), float(c[0])
         assert torch.isfinite(rgb).all() and torch.isfinite(out["loss_coarse"]).all()
         t_train = float(np.mean([a.elapsed_time(b) for a, b in phase["train"]])) * 1e-3
         t_render = float(np.mean([a.elapsed_time(b) for a, b in phase["render"]])) * 1e-3
         return {"dt": dt, "steps": steps, "value": (n_rand + args.render_rays) * world * steps / dt, "n_rand": n_rand,
                 "ms_per_step": dt / steps * 1e3, "k_ms": float(np.mean([a.elapsed_time(b) for a, b in ev])),
                 "t_train": t_train, "t_render": t_render, "loss_coarse": float(out["loss_coarse"]),
-                "loss_fine": float(out.get("loss_fine", torch.zeros(1)))}
+                "loss_fine": float(out.get("loss_fine", torch.zeros(1))), "comm_ms_per_step": comm_ms, "trainer": tr}
+
+    def frame_leg(tr):
+        """ONE full frame through the PUBLIC API, `render.render(H, W, K, chunk=32768, c2w=...)` (rendering/render.py:268-345 of
+        the reference): rays generated inside, 20 chunks of 32768 (the last one ragged at 800 x 800), coarse + importance +
+        fine per chunk, every output of the reference's return list (rgb / disp / acc + extras z_vals, weights, *_coarse)
+        materialised and reshaped to the ray grid.  One untimed frame first (allocator warm-up), then one timed."""
+        from nerf_meets_mlx_amd.models.NeRF import NetworkQuery
+        kw = {"network_query_fn": NetworkQuery(None, None, 1024 * 64, True), "render_rays_func": render.render_rays_eval,
+              "network_coarse": tr.coarse, "network_fine": tr.fine, "n_depth_samples": 64, "N_importance": NI,
+              "white_bkgd": True, "perturb": False, "raw_noise_std": 0, "lindisp": False}
+        c2w = rposes[40][:3, :4]
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rgb, disp, acc, extras = render.render(H, W, K, chunk=1024 * 32, c2w=c2w, ndc=False, near=2.0, far=6.0,
+                                                   use_viewdirs=True, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert tuple(rgb.shape) == (H, W, 3) and torch.isfinite(rgb).all() and "z_vals" in extras and "weights" in extras
+        return {"api": "render.render(H, W, K, chunk=32768, c2w=..., **render_kwargs_test)", "rays": H * W, "seconds": dt,
+                "rays_per_s": H * W / dt, "chunks": (H * W + 32767) // 32768,
+                "outputs": ["rgb_map", "disp_map", "acc_map"] + sorted(extras.keys())}
 
     m = measure(16, args.steps, args.warmup)                       # THE timed region of the contract
     dt, value, k_ms, t_train, t_render = m["dt"], m["value"], m["k_ms"], m["t_train"], m["t_render"]
@@ -192,8 +226,12 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": (f"configs[2]: Lego {H}x{W} coarse+fine NeRF (64+{NI} importance samples), " if NI > 0 else
                                 f"configs[1]: Lego {H}x{W} coarse-only NeRF (64 samples/ray), ")
-                               + f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU",
+                               + f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU; "
+                               "HEADLINE `value` = the DECLARED REDUCED-PRECISION MODE (bf16 MFMA operands, fp32 accumulate; the "
+                               "reference computes in float32) -- the same step at the reference's float32 arithmetic is "
+                               "`reference_precision_value` (N = 1 line)",
                    "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
+        "comm_ms_per_step": m["comm_ms_per_step"],
         "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
         "train_mfma_frac": train_tf / BF16_MFMA_PEAK_TFLOPS, "render_mfma_frac": render_tf / BF16_MFMA_PEAK_TFLOPS,
         # the training phase against its other roofline: bf16 activations + dZ written once (321 KiB per 32-sample tile)
@@ -214,6 +252,7 @@ def main():
         if ms["dt"] < args.sustain_seconds:                      # the burst's step time underestimated it (first-run effects): once more, scaled
             n_sus = int(np.ceil(n_sus * args.sustain_seconds * 1.1 / ms["dt"]))
             ms = measure(16, n_sus, 2)
+        ms.pop("trainer", None)
         line["sustained"] = {"seconds": ms["dt"], "steps": n_sus, "value": ms["value"], "unit": "rays/s",
                              "ms_per_step": ms["ms_per_step"], "ms_per_launch": ms["k_ms"],
                              "roofline_frac": flop / (ms["k_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
@@ -223,6 +262,7 @@ def main():
         # default 4096, config_parser.py:17); same step, launch overheads weigh more
         if args.n_rand != 1024:
             ml = measure(16, args.steps, args.warmup, n_rand=1024)
+            ml.pop("trainer", None)
             line["lego_batch"] = {"n_rand_per_gpu": 1024, "value": ml["value"], "unit": "rays/s", "steps": ml["steps"],
                                   "ms_per_step": ml["ms_per_step"], "train_rays_per_s": 1024 / ml["t_train"],
                                   "render_rays_per_s": args.render_rays / ml["t_render"],
@@ -239,6 +279,17 @@ def main():
                         "roofline": {"bound": "mfma", "kernel": "mlp32_fwd_kernel (render fine pass)", "achieved": a32,
                                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a32 / FP32_MFMA_PEAK_TFLOPS,
                                      "ms_per_launch": m32["k_ms"], "samples_per_launch": args.render_rays * n_fine}}
+        # the reference-precision measurement where the driver parses it: top level + inside `roofline`
+        line["reference_precision_value"] = m32["value"]
+        line["reference_precision_unit"] = "rays/s (same step, float32 operands: models/NeRF.py:201-243 of the reference runs in MLX float32)"
+        line["roofline"]["reference_precision"] = {
+            "kernel": "mlp32_fwd_kernel (render fine pass, v_mfma_f32_32x32x2_f32)", "dtype": "f32", "value": m32["value"],
+            "unit": "rays/s", "steps": args.fp32_steps, "ms_per_step": m32["ms_per_step"], "achieved": a32,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "achieved_unit": "TFLOP/s", "frac": a32 / FP32_MFMA_PEAK_TFLOPS,
+            "ms_per_launch": m32["k_ms"], "samples_per_launch": args.render_rays * n_fine,
+            "train_rays_per_s": args.n_rand / m32["t_train"], "render_rays_per_s": args.render_rays / m32["t_render"]}
+        # ---- frame: one full 800 x 800 frame through the public render.render() API, both precisions
+        line["frame"] = {"bf16": frame_leg(m["trainer"]), "f32": frame_leg(m32["trainer"])}
         # ---- ngp: BASELINE configs[4] (hash grid + 2x64 MLP), its own step and roofline (the table-gradient scatter)
         ngp_line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev)
         line["ngp"] = {k: ngp_line[k] for k in ("value", "unit", "ms_per_step", "steps", "train_rays_per_s_per_gpu",
@@ -388,10 +439,10 @@ def _host_cores():
 
 def cpu_baseline(args):
     """The CPU oracle (op-for-op torch-CPU fp32 restatement of the reference path, `kind: port`) at the size SURVEY
-    8(d) specifies: training at B = 1024 rays (lego.txt N_rand), 3 warm-up + up to 20 timed steps, and a render slice
-    of 65 536 rays in 4096-ray chunks (coarse 64 + fine 64+128 like the GPU step; coarse-only when --n-importance 0).
-    Each leg is time-boxed (--cpu-seconds, default 30 s) so that a slow host still finishes: the steps / rays actually timed are in
-    `sample`.  `value` combines the two legs in the GPU step's train : render ray mix."""
+    8(d) specifies: training at B = 1024 rays (lego.txt N_rand), 3 warm-up + 20 timed steps (about 100 s on 16 cores; only
+    a safety cap, --cpu-train-cap, can cut it short), and a render slice of 65 536 rays in 4096-ray chunks (coarse 64 + fine
+    64+128 like the GPU step; coarse-only when --n-importance 0), time-boxed by --cpu-seconds: the steps / rays actually
+    timed are in `sample`.  `value` combines the two legs in the GPU step's train : render ray mix."""
     from oracle import nerf_oracle as O
     cores = _host_cores()
     torch.set_num_threads(cores)
@@ -408,7 +459,7 @@ def cpu_baseline(args):
         tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))
     t0 = time.perf_counter()
     steps = 0
-    while steps < 20 and (steps < 3 or time.perf_counter() - t0 < args.cpu_seconds):
+    while steps < 20 and time.perf_counter() - t0 < args.cpu_train_cap:    # 20 timed iterations after 3 warm-ups
         tr.step(o[:b_train], d[:b_train], y, torch.rand(b_train, un, generator=g))
         steps += 1
     t_train = time.perf_counter() - t0

@@ -70,6 +70,10 @@ class HashNeRF:
         if self.deterministic:
             self.enc.grad = torch.zeros(self.enc.tables.shape, dtype=torch.int64, device=self.enc.tables.device)
         self.table = _Flat(self.enc.tables, self.enc.grad)
+        # True while the accumulator is known to hold zeros (fresh, or consumed-and-cleared by nerf_adam_step_ex); any
+        # scatter makes it dirty.  NGPTrainer.train_step only skips the clear when this says so: a public backward() call,
+        # or a step that raised between the scatter and Adam, leaves a gradient behind that must not be added to the next one.
+        self._grad_clean = True
         ng = max(1, min(int(level_groups), n_levels))
         self.level_groups = [(n_levels * i // ng, n_levels * (i + 1) // ng) for i in range(ng)]
         self.on_group_done = None           # NGPTrainer: called after each level group's scatter is enqueued (lo, hi)
@@ -138,6 +142,7 @@ class HashNeRF:
         e = self.enc
         if not accumulate:
             e.grad.zero_()
+        self._grad_clean = False
         if self.timing is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -183,7 +188,7 @@ class NGPTrainer(Trainer):
     def train_step(self, rays=None, target=None, u=None) -> Dict[str, torch.Tensor]:
         if rays is None:
             rays, target = self.sample_batch()
-        self.opt.learning_rate = self.lrate * (0.1 ** (self.it / (self.lrate_decay * 1000)))
+        self._opt.learning_rate = self.lrate * (0.1 ** (self.it / (self.lrate_decay * 1000)))
         z = sampling.sample_coarse(rays, self.n)
         raw = self.field.query(rays, z, train=True)
         loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, self.white_bkgd)
@@ -204,16 +209,18 @@ class NGPTrainer(Trainer):
                     return torch.distributed.all_reduce(t, async_op=True)
             self.field.on_mlp_grads = lambda g: mlp_work.append(on_comm(g))
             self.field.on_group_done = lambda lo, hi: pending.append(on_comm(flat[lo * per_level:hi * per_level]))
-        g_mlp, g_tab = self.field.backward(d_raw, accumulate=True)       # zeroed by the previous step's table Adam
+        # accumulate (no clear) only when the accumulator is KNOWN to be zero: left so by the previous step's table Adam
+        g_mlp, g_tab = self.field.backward(d_raw, accumulate=self.field._grad_clean)
         self.field.on_group_done = self.field.on_mlp_grads = None
         for w in mlp_work:
             w.wait()
-        self.opt.update(self.field.mlp, g_mlp, grad_scale=1.0 / self.world)
+        self._opt.update(self.field.mlp, g_mlp, grad_scale=1.0 / self.world)      # _opt: the `opt` property would join the comm stream
         for w in pending:
             w.wait()
         if pending:
             torch.cuda.current_stream().wait_stream(self._comm)
-        self.opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world, zero_grads=True)    # reads g, writes 0
+        self._opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world, zero_grads=True)    # reads g, writes 0
+        self.field._grad_clean = True
         self.it += 1
         return {"loss_coarse": loss}
 

@@ -13,6 +13,13 @@ Differences from the reference are mechanical only: ray generation, pixel select
 importance sampler run as HIP kernels instead of numpy / torch-CPU, nothing leaves the device, and
 with world_size > 1 each rank draws its own rays and the flat gradients are summed with ONE RCCL
 all-reduce per network step (mean over ranks).
+
+Round 4: with world_size > 1 the collectives and the Adam steps run on a COMM STREAM, in program order
+(AR_coarse, Adam_coarse, AR_fine, Adam_fine, AR_coarse', ...).  The compute stream joins it after the coarse step
+(the re-render at :270 reads the updated coarse weights) but NOT after the fine step: the fine network's all-reduce +
+Adam overlap the next iteration's batch sampling and coarse forward / backward, which read neither the fine weights
+nor -- until the next coarse Adam, which is queued behind on the same stream -- the shared Adam moments (Q7).  Same
+arithmetic in the same order as the serial schedule: weights are bit-identical (tests/test_gpu_multirank.py).
 """
 import os
 from typing import Dict, Optional
@@ -30,7 +37,7 @@ class Trainer:
     def __init__(self, images: torch.Tensor, poses: torch.Tensor, K, near: float = 2.0, far: float = 6.0,
                  N_rand: int = 1024, n_depth_samples: int = 64, N_importance: int = 128, lrate: float = 5e-4,
                  lrate_decay: int = 500, white_bkgd: bool = True, ref_quirks: bool = True, seed: int = 0,
-                 device="cuda", chunk: int = 1024 * 32, precision: int = 16):
+                 device="cuda", chunk: int = 1024 * 32, precision: int = 16, overlap_comm: bool = True):
         self.device = torch.device(device)
         self.images = images.to(self.device, torch.float32).contiguous()      # [N,H,W,3], white-composited
         self.poses = poses.float().cpu()
@@ -55,9 +62,35 @@ class Trainer:
             self.fine.name = "fine"
         self.opt = Adam(lrate, betas=(0.9, 0.999), shared_state=ref_quirks)
         self.it = 0
+        # collectives + Adam steps of a multi-rank run (see the module docstring); None: everything on the caller's stream
+        self._comm = torch.cuda.Stream(device=self.device) if (self.world > 1 and overlap_comm) else None
         self.gen = torch.Generator(device=self.device)                 # evaluation-time uniforms (render_rays without u)
         self.gen.manual_seed(parallel.rank_seed(seed, self.rank, 2))
         self._train_gen = torch.Generator(device=self.device)          # re-seeded per iteration (train_uniforms)
+
+    # `fine` and `opt` are touched by work that may still be queued on the comm stream when train_step returns: reading
+    # them from outside joins that stream first (a stream-side wait, no host block).  The hot loop uses _fine / _opt.
+    def _join_comm(self):
+        if getattr(self, "_comm", None) is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._comm)
+
+    @property
+    def fine(self):
+        self._join_comm()
+        return self._fine
+
+    @fine.setter
+    def fine(self, m):
+        self._fine = m
+
+    @property
+    def opt(self):
+        self._join_comm()
+        return self._opt
+
+    @opt.setter
+    def opt(self, o):
+        self._opt = o
 
     def image_choice(self) -> int:
         """np.random.choice(i_train) of iteration `self.it` (`__test_nerf.py:202`)."""
@@ -69,12 +102,21 @@ class Trainer:
         return torch.rand(B, self.N, device=self.device, generator=self._train_gen)
 
     # ---------------------------------------------------------------- one network step
-    def _step_net(self, model: NeRF, rays, z, target, white: bool):
+    def _step_net(self, model: NeRF, rays, z, target, white: bool, join: bool = True):
         raw = model.query(rays, z, ref_quirks=self.q, train=True)
         loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, white)      # raw2outputs + MSE + adjoint
         grads = model.backward(d_raw)
-        parallel.allreduce_sum_(grads)                                         # C1: the only collective
-        self.opt.update(model, grads, grad_scale=1.0 / self.world)
+        if self._comm is None:
+            parallel.allreduce_sum_(grads)                                     # C1: the only collective
+            self._opt.update(model, grads, grad_scale=1.0 / self.world)
+            return loss
+        cur = torch.cuda.current_stream(self.device)
+        self._comm.wait_stream(cur)                                            # the gradient is complete
+        with torch.cuda.stream(self._comm):
+            parallel.allreduce_sum_(grads)
+            self._opt.update(model, grads, grad_scale=1.0 / self.world)       # Adam kernel on the comm stream (N.stream())
+        if join:
+            cur.wait_stream(self._comm)
         return loss
 
     def sample_batch(self, pixel_idx: Optional[torch.Tensor] = None, img_i: Optional[int] = None):
@@ -92,17 +134,18 @@ class Trainer:
         """One iteration of `__test_nerf.py:200-305`.  Losses are device scalars (no host sync)."""
         if rays is None:
             rays, target = self.sample_batch()
-        self.opt.learning_rate = self.lrate * (0.1 ** (self.it / (self.lrate_decay * 1000)))   # set after iter it-1
+        self._opt.learning_rate = self.lrate * (0.1 ** (self.it / (self.lrate_decay * 1000)))  # a host float, passed by value
         z = sampling.sample_coarse(rays, self.n)                               # perturb = 0 in quirk mode (Q5)
         out = {"loss_coarse": self._step_net(self.coarse, rays, z, target, self.white_bkgd)}
-        if self.fine is not None:
+        if self._fine is not None:
             raw = self.coarse.query(rays, z, ref_quirks=self.q)                # updated coarse net, no grad (:270)
             _, _, _, weights, _ = render.composite(raw, z, rays, 0.0, self.white_bkgd)
             if u is None:
                 u = self.train_uniforms(rays.shape[0])
             _, z_fine = sampling.importance_sample(z, weights, self.N, u=u)
             white_fine = self.white_bkgd if not self.q else False               # Q8
-            out["loss_fine"] = self._step_net(self.fine, rays, z_fine, target, white_fine)
+            # no join: the fine all-reduce + Adam run under the next iteration's sampling and coarse forward / backward
+            out["loss_fine"] = self._step_net(self._fine, rays, z_fine, target, white_fine, join=False)
         self.it += 1
         return out
 

@@ -71,10 +71,22 @@ def counter_seed(seed: int, rank: int, stream: int, it: int) -> int:
     return x >> 1
 
 
+# bench.py: a list here receives one (start, end) torch.cuda.Event pair per gradient all-reduce, recorded on the stream the
+# collective is issued on (the trainers' comm stream): comm_ms_per_step of the scaling runs.  None = no timing.
+comm_timing = None
+
+
 def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks of the flat gradient buffer; identity for one process."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if comm_timing is not None and flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            e1.record()
+            comm_timing.append((e0, e1))
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 

@@ -44,9 +44,18 @@ def _worker(rank, world, port, q, tmp):
     frame_ok = (frame is None) if rank else (tuple(frame.shape) == (16, 16, 3) and bool(torch.isfinite(frame).all()))
     # ---- multi-rank resume: 2 iterations, rank 0 saves, ALL ranks load, 2 more == 4 uninterrupted
     mk = lambda: Trainer(imgs, poses, K, N_rand=64, n_depth_samples=64, N_importance=128, seed=4, device="cuda")
+    # round 4: the default trainer queues collectives + Adam on a comm stream and does not join it after the fine step
+    # (engine/trainer.py); the serial schedule (overlap_comm=False) must give the same weights and moments bit for bit.
+    # Compared right after the last step with NO device synchronisation: reading `.fine` / `.opt` joins the comm stream.
+    ser = Trainer(imgs, poses, K, N_rand=64, n_depth_samples=64, N_importance=128, seed=4, device="cuda", overlap_comm=False)
+    for _ in range(4):
+        ser.train_step()
     full = mk()
     for _ in range(4):
         full.train_step()
+    overlap_ok = (full._comm is not None and ser._comm is None
+                  and torch.equal(full.fine.params, ser.fine.params) and torch.equal(full.coarse.params, ser.coarse.params)
+                  and all(torch.equal(a, b) for a, b in zip(full.opt.state["shared"], ser.opt.state["shared"])))
     part = mk()
     for _ in range(2):
         part.train_step()
@@ -66,7 +75,7 @@ def _worker(rank, world, port, q, tmp):
     for _ in range(2):
         res.train_step()
     torch.cuda.synchronize()
-    resume_ok = (own_stream and differ2 and u_same and torch.equal(res.coarse.params, full.coarse.params)
+    resume_ok = (overlap_ok and own_stream and differ2 and u_same and torch.equal(res.coarse.params, full.coarse.params)
                  and torch.equal(res.fine.params, full.fine.params))
     q.put((rank, ok, differ, frame_ok and resume_ok, float(out["loss_coarse"])))
     dist.destroy_process_group()

@@ -146,9 +146,14 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
         ot = O.OracleTrainer(arch, 64, a.n_importance, seed=seed, lrate_decay=a.lrate_decay, ref_quirks=quirks, device=dev)
         dead["oracle"] = DeadTracker()
     idx = torch.arange(H * W, device=dev, dtype=torch.int64)
+    if 0 < getattr(a, "eval_pixels", 0) < H * W:
+        # held-out PSNR on a FIXED pixel subset of every test view (the same for every seed, arm and checkpoint): an
+        # unbiased estimate of the view's MSE that keeps the fp32 arm's evaluations from dominating a 20 000-iteration run
+        idx = torch.randperm(H * W, generator=torch.Generator().manual_seed(11))[:a.eval_pixels].sort().values.to(dev)
     test_rays = [ray.gen_rays(H, W, K, p[:3, :4].cpu().numpy(), 2.0, 6.0, idx) for p in test_poses]
+    test_imgs = [img.reshape(-1, 3)[idx] for img in test_imgs]
     NI = max(a.n_importance, 1)
-    u_eval = torch.rand(H * W, NI, generator=torch.Generator().manual_seed(7)).to(dev)
+    u_eval = torch.rand(idx.numel(), NI, generator=torch.Generator().manual_seed(7)).to(dev)
 
     def psnr_of(tr):
         vals = []
@@ -165,7 +170,7 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
             vals = []
             for img, rays in zip(test_imgs, test_rays):
                 outs = []
-                for s in range(0, H * W, 8192):
+                for s in range(0, rays.shape[0], 8192):
                     r = rays[s:s + 8192]
                     o = (O.render_rays_eval(arch, pc, pf, r, 64, a.n_importance, u_eval[s:s + 8192], True, False, quirks)
                          if a.n_importance > 0 else O.render_rays(arch, pc, r, 64, True, ref_quirks=quirks))
@@ -259,6 +264,7 @@ def main():
                     "noise floor of this training recipe: what two runs of ONE arithmetic look like)")
     ap.add_argument("--resync", action="store_true", help="after every checkpoint copy the fp32 arm's state into the bf16 arm: each "
                     "checkpoint's delta is then the drift of ONE interval from a common state (short-horizon bias estimator)")
+    ap.add_argument("--eval-pixels", type=int, default=0, help="evaluate the held-out PSNR on this many fixed pixels per test view (0: all)")
     ap.add_argument("--out", default="", help="also append every line to this file")
     a = ap.parse_args()
     fp = open(a.out, "a") if a.out else None
