@@ -152,7 +152,10 @@ int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, in
 /* The same for levels [level_lo, level_hi) only (the launches of disjoint level groups can be followed one by one by the
  * all-reduce of their slice of d_tables on another stream), and optionally DETERMINISTIC: fixed_point = 1 makes d_tables
  * an int64 [L,T,F] array of 2^-52 fixed-point accumulators added with integer atomics (associative: the result does not
- * depend on the order the memory side serves the requests; float atomics do).  nerf_adam_step_ex consumes either form.  */
+ * depend on the order the memory side serves the requests; float atomics do).  nerf_adam_step_ex consumes either form.
+ * Range of the fixed-point form: an addend with |v| > 256 saturates to +-256, a NaN / Inf addend adds 2^61 units, and
+ * nerf_adam_step_ex reads every accumulator outside (-2^60, 2^60) units -- saturated, poisoned, or a per-entry sum beyond
+ * +-256, also after a cross-rank sum -- as a NaN gradient: a diverged run surfaces as NaN parameters, as with float atomics. */
 int nerf_hashgrid_backward_ex(const float* x, int64_t M, const float* d_out, int L, int log2_T, int F,
                               const int* resolutions_host, int level_lo, int level_hi, int fixed_point, void* d_tables,
                               void* stream);
@@ -229,7 +232,15 @@ typedef struct nerf_mlp_arch {
                      * on v_mfma_f32_32x32x2_f32, sinf / cosf encodings; 8 x 256 view model only.  Read by
                      * nerf_mlp_packed_bytes / nerf_mlp_pack (an fp32 model's image carries the fp32 weight streams behind
                      * the bf16 one), nerf_mlp_acts_bytes / nerf_mlp_dz_bytes (fp32 stores are larger) and every launch:
-                     * use ONE arch value per model for all of them.                                                  */
+                     * use ONE arch value per model for all of them.
+                     * 22 (round 4): the reference's float32 TOLERANCE on the 16-bit matrix pipe.  Calls that keep no
+                     * activations (nerf_mlp_forward, nerf_query_fused / nerf_render_rays_fused with acts == NULL) run the
+                     * split-fp16 kernel of csrc/mlp22.hip: every float32 operand x = hi + lo 2^-11 as two fp16 numbers
+                     * (22 significand bits), a product = hi hi + 2^-11 (hi lo + lo hi) on v_mfma_f32_16x16x32_f16 with
+                     * fp32 accumulate, float32-accurate encodings; operands must stay inside the fp16 range
+                     * (|activation| < 65504: an overflow becomes inf / NaN in the output, never a silent wrong value).
+                     * Everything that keeps activations (training forward, backward) runs the precision-32 kernels, so a
+                     * precision-22 model trains exactly like a precision-32 one; its image carries all three streams. */
 } nerf_mlp_arch;
 
 int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch);

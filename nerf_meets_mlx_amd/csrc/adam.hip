@@ -31,7 +31,12 @@ __global__ void __launch_bounds__(256) adam_ex_kernel(float* __restrict__ p, voi
   long long* gi64 = static_cast<long long*>(gv);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
     float gi;
-    if (FIXED) { gi = (float)((double)gi64[i] * (1.0 / NERF_HASH_FIX_SCALE)) * gscale; if (ZERO) gi64[i] = 0; }
+    if (FIXED) {
+      const long long a = gi64[i];
+      gi = (float)((double)a * (1.0 / NERF_HASH_FIX_SCALE)) * gscale;
+      if (nerf_fixed_is_poisoned(a)) gi = __builtin_nanf("");           // saturated / non-finite addend or overflowing sum (hash_common.h)
+      if (ZERO) gi64[i] = 0;
+    }
     else { gi = gf[i] * gscale; if (ZERO) gf[i] = 0.0f; }
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;

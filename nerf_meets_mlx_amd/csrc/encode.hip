@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(256) ngp_dir_rows_kernel(const float* __restri
 // added with an INTEGER atomic: integer addition is associative, so the accumulated table gradient does not depend on
 // the order in which the memory side serves the requests -- bit-reproducible run to run, unlike float atomics -- and it
 // is also the exactly rounded sum of the quantised addends (|addend| < 2^11, resolution 2^-52: finer than float32 for
-// every addend above 3e-9, and Adam's eps = 1e-8 hides what is below).  nerf_adam_step_ex reads the accumulators.
+// every addend above 3e-9, and Adam's eps = 1e-8 hides what is below; out-of-range and non-finite addends: nerf_to_fixed,
+// hash_common.h).  nerf_adam_step_ex reads the accumulators.
 template <int F, int LG, bool FIXED>
 __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t M,
                                                            void* __restrict__ d_tables_v, const float* __restrict__ d_out,
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t 
   float* d_tables = static_cast<float*>(d_tables_v);
   unsigned long long* d_fixed = static_cast<unsigned long long*>(d_tables_v);
   auto add = [&](size_t idx, float v) {
-    if (FIXED) atomicAdd(d_fixed + idx, (unsigned long long)(long long)__double2ll_rn((double)v * NERF_HASH_FIX_SCALE));
+    if (FIXED) atomicAdd(d_fixed + idx, (unsigned long long)nerf_to_fixed(v));
     else atomicAdd(d_tables + idx, v);
   };
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_combine_kernel(PointSrc ps, 
           slot = (slot + 1) & (HC_CAP - 1);
         }
         if (FIXED) {
-          const unsigned long long q64 = (unsigned long long)(long long)__double2ll_rn((double)val[c] * NERF_HASH_FIX_SCALE);
+          const unsigned long long q64 = (unsigned long long)nerf_to_fixed(val[c]);
           if (found) atomicAdd(reinterpret_cast<unsigned long long*>(&vals[slot * F + f]), q64);
           else atomicAdd(d_fixed + tb + (size_t)idx[c] * F + f, q64);
         } else {

@@ -35,6 +35,21 @@ struct ResTab { float res[32]; };
 // fixed-point unit of the deterministic table-gradient accumulators (int64): 2^-52
 #define NERF_HASH_FIX_SHIFT 52
 #define NERF_HASH_FIX_SCALE 4503599627370496.0
+// Representable range and failure behaviour (include/nerf_hip.h, nerf_hashgrid_backward_rays_ex): a finite addend with
+// |v| > 256 saturates to +-2^60 units (= +-256), a NaN / Inf addend adds 2^61 units; nerf_adam_step_ex turns every
+// accumulator outside (-2^60, 2^60) -- a saturated addend, a poisoned one, or a per-entry sum that large, also after the
+// cross-rank all-reduce -- back into a NaN gradient, so that a diverged run surfaces as NaN parameters exactly as it does
+// with float atomics instead of continuing on wrapped integers.  (k poisoned addends on one entry sum to k 2^61 mod 2^64,
+// which is inside the window only for k = 0 mod 8: a diverged batch poisons thousands of entries, 7 of 8 of them stay NaN.)
+#define NERF_HASH_FIX_LIMIT 256.0f
+__device__ __forceinline__ long long nerf_to_fixed(float v) {
+  if (!(__builtin_fabsf(v) <= NERF_HASH_FIX_LIMIT))
+    return (v != v || __builtin_isinf(v)) ? (1ll << 61) : (v > 0.0f ? (1ll << 60) : -(1ll << 60));
+  return __double2ll_rn((double)v * NERF_HASH_FIX_SCALE);
+}
+__device__ __forceinline__ bool nerf_fixed_is_poisoned(long long a) {
+  return (unsigned long long)(a + (1ll << 60)) >= (1ull << 61);        // a outside [-2^60, 2^60)
+}
 
 __device__ __forceinline__ uint32_t hash3(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t mask) {
   return ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) & mask;     // uint32 wrap-around, mod T = & (T-1)

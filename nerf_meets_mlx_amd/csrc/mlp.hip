@@ -22,68 +22,23 @@
 // second layout: image-fitting model (namespace LI) | third layout: 2 x 64 model of configs[4] (namespace LN) |
 // C ABI entry points.
 #include "common.h"
+#include "mlp_ring.h"
+#include "mlp_layout.h"
 #include "hash_common.h"
 #include "mlp_params.h"
 #include "mlp32.h"
+#include "mlp22.h"
 #include <string.h>
 #include <mutex>
 #include <unordered_map>
 
-#ifndef NERF_SPREAD_DMA
-#define NERF_SPREAD_DMA 1     // ring refill: one DMA per quarter chunk interval instead of a burst of 4
-#endif
-#ifndef NERF_ABLATE
-#define NERF_ABLATE 0
-#endif
-// (Round 1 had a switch NERF_EXACT_VMCNT that counted the fragment stores of the last three chunk intervals into the ring's
-// vmcnt wait: no gain in the training forward, spills in the backward chain -- and, as the fp32 kernels showed in round 3,
-// WRONG in principle: stores complete out of order with respect to loads, so a wait may only count younger LOADS
-// (mlp32.hip, frag_wait_n).  Removed.)
-// A/B switches (both default on): non-temporal DMA loads in the dW kernel / non-temporal fragment stores
-#ifndef NERF_NT_DW_LOADS
-#define NERF_NT_DW_LOADS 1
-#endif
 
 namespace nerf {
 
 extern int g_hash_combine_max_res;        // encode.hip
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// ------------------------------------------------------------------------------------------
-// static layout of the one supported architecture (8 x 256, skip 4, view head)
-// ------------------------------------------------------------------------------------------
-namespace L {
-// float32 parameter offsets P_*: mlp_params.h (shared with the fp32 reference-precision kernels of mlp32.hip)
-
-// forward weight stream, 1 KiB fragments in consumption order
-constexpr int F_L0 = 0, F_L1 = 32, F_L5 = 544, F_L6 = 704, F_L7 = 832, F_FA = 960, F_DIR = 1104, F_RGB = 1176;
-constexpr int F_TOTAL = 1184;
-// backward (transposed) weight stream
-constexpr int B_RGB = 0, B_DIR = 4, B_FA = 68, B_L7 = 204, B_L6 = 332, B_L5 = 460, B_L4 = 588;
-constexpr int B_TOTAL = 1100, B_PADDED = 1120;    // padded with zero fragments to whole 32-fragment ring chunks
-// fp32 bias slots
-constexpr int BI_FEAT = 2048, BI_ALPHA = 2304, BI_DIR = 2336, BI_RGB = 2464, BI_TOTAL = 2496;
-constexpr int F16_TOTAL = 1172, F16_PADDED = 1184;   // forward stream of the 16x16x32 variant (inference only)
-constexpr int64_t F16_OFFSET = (int64_t)(F_TOTAL + B_PADDED) * 1024 + BI_TOTAL * 4;    // appended after the bias slots
-constexpr int64_t PACKED_BYTES = F16_OFFSET + (int64_t)F16_PADDED * 1024;
-
-// activation store: fragment slots per 32-sample tile
-constexpr int A_PE = 0, A_DPE = 4, A_H0 = 6;       // H_l at A_H0 + 16 l, l = 0..7
-constexpr int A_FEAT = 134, A_HD = 150;
-// ReLU sign bits of H0..H7 and HD for the backward chain: one 16-byte word per lane and layer (layout: see
-// finish_quarter), so the chain reads 9 KiB per tile instead of 150 KiB
-constexpr int A_MASK = 158, A_SLOTS = 167;
-// gradient store
-constexpr int Z_L0 = 0;                            // dZ_l at 16 l, l = 0..7
-constexpr int Z_F = 128, Z_A = 144, Z_D = 145, Z_RGB = 153, Z_SLOTS = 154;
-}  // namespace L
-
-// element j of lane half h in k-step ks  <->  feature index
-__host__ __device__ constexpr int kperm(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
+// static layout (namespace L), kperm: mlp_layout.h
 
 // ------------------------------------------------------------------------------------------
 // weight packing: fp32 master parameters -> bf16 MFMA fragments (+ fp32 bias slots)
@@ -179,7 +134,6 @@ __device__ __forceinline__ void pack_part(int tid, const float* __restrict__ p, 
 // ------------------------------------------------------------------------------------------
 // positional encoding straight into B-operand fragments
 // ------------------------------------------------------------------------------------------
-struct PeFreq { float pos[10]; float dir[4]; };
 
 struct Chan { int kind, dim, band; };   // kind: 0 identity, 1 sin, 2 cos, 3 zero pad
 __host__ __device__ constexpr Chan chan_of(int c, int limit) {
@@ -226,161 +180,7 @@ __device__ __forceinline__ bf16x8 row_frag(const float* __restrict__ row, int ks
   return v;
 }
 
-// ------------------------------------------------------------------------------------------
-// weight sources: where a wave gets the 1 KiB A-operand fragment `f` of the packed stream from
-// ------------------------------------------------------------------------------------------
-// one 1 KiB fragment global -> LDS with no VGPR round trip (lane i lands at lds_addr + 16 i).
-// Inline asm on purpose: hipcc treats the builtin as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front
-// of the next ds_read of the same array, which drains the whole prefetch ring every tile.  Hidden in asm, the
-// DMAs are ordered by OUR counted `s_waitcnt vmcnt(N)` + s_barrier (cdna_hip_programming.md 5.7).  M0 carries
-// the LDS byte address and is restored because the compiler owns it.
-__device__ __forceinline__ void dma_frag(const void* gsrc_lane, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
-}
-// same with a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (no 64-bit VGPR address per fragment,
-// which hipcc would otherwise hoist out of persistent loops and spill)
-__device__ __forceinline__ void dma_frag_s(const void* gbase_uniform, unsigned lane_off, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(lane_off), "s"(gbase_uniform), "s"(lds_addr) : "memory");
-}
-// non-temporal form for bytes that are read exactly once (the dW kernel's dZ / activation stream)
-__device__ __forceinline__ void dma_frag_nt(const void* gsrc_lane, unsigned lds_addr) {
-  unsigned keep;
-#if NERF_NT_DW_LOADS
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
-#else
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
-#endif
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-  return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
-}
-
-// (1) straight from global memory / L1: no synchronisation between waves (variants 1 and 2)
-struct GlobalW {
-  const bf16x8* __restrict__ wlane;    // stream base + lane
-  const float* __restrict__ bias;
-  __device__ __forceinline__ bf16x8 frag(int f, int) { return wlane[f * 64]; }
-  __device__ __forceinline__ void note_stores(int) {}
-  __device__ __forceinline__ float4 bias4(int slot) { return *reinterpret_cast<const float4*>(bias + slot); }
-};
-
-// (2) LDS ring fed by LDS-DMA and shared by the 8 waves of a workgroup (variant 3).  The stream is consumed
-// strictly in order by every wave; chunk = 32 fragments (32 KiB), 4 stages, 3 chunks in flight.  At a chunk
-// boundary every wave: waits for ITS share of the chunk (counted vmcnt: the 2 younger chunks stay in flight),
-// barrier (everybody's share landed; everybody finished reading the previous chunk), then refills the stage that
-// just became free with the chunk 3 ahead (wrapping to the next pass over the weights).
-constexpr int RING_CHUNK = 32, RING_STAGES = 4, RING_STAGE_BYTES = RING_CHUNK * 1024;
-constexpr int RING_BIAS_OFF = RING_STAGES * RING_STAGE_BYTES;          // fp32 bias slots behind the ring
-constexpr int RING_LDS_BYTES = RING_BIAS_OFF + 2560 * 4;
-
-extern __shared__ __attribute__((aligned(16))) char ring_smem[];
-
-// RING_GROUP = fragments per software-pipeline group (one group in use, one in flight); TOTAL = fragments
-// consumed per pass (multiple of RING_GROUP)
-// CHUNK / STAGES: fragments per ring stage and stages (default 32 x 4 = 128 KiB for one 8-wave workgroup per CU; 16 x 4 =
-// 64 KiB lets two independent 4-wave workgroups share a CU, see mlp_fwd_ring_kernel)
-template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES>
-struct RingW {
-  static constexpr int DPW = CHUNK / NW;               // DMAs per wave per chunk
-  static constexpr int STAGE_BYTES = CHUNK * 1024, BIAS_OFF = STAGES * STAGE_BYTES, LDS_BYTES = BIAS_OFF + 2560 * 4;
-  static_assert(DPW * NW == CHUNK && (DPW == 4 || DPW == 8), "ring: 4 or 8 DMAs per wave per chunk");
-  const char* __restrict__ wsrc;       // global stream base (uniform)
-  unsigned lane16;                     // 16 * lane
-  unsigned lds0;                       // LDS byte address of ring_smem (M0 values are absolute)
-  int wv;                              // wave id in the workgroup (uniform)
-  int ring_pos;                        // stage of the chunk the prefetch reads from
-  int woff;                            // ring_pos * STAGE + 16 * lane
-  bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
-
-  // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k
-  __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
-    const int i = wv + NW * k;
-    dma_frag_s(wsrc + ((int64_t)chunk * CHUNK + i) * 1024, lane16, lds0 + stage * STAGE_BYTES + i * 1024);
-  }
-  __device__ __forceinline__ void issue(int chunk, int stage) {
-#pragma unroll
-    for (int k = 0; k < DPW; ++k) issue_one(chunk, stage, k);
-  }
-  // Whole chunks refill their freed stage one DMA per quarter of the interval (a burst of 4 right behind the barrier
-  // stalls both waves of a SIMD on the VMEM issue path at once); the partial last chunk of a pass keeps the burst.
-  // (not in the activation-storing training forward, RING_GROUP 2: it is at the VGPR limit and HBM-bound anyway)
-  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && RING_GROUP == 4 && (c + 1) * CHUNK <= TOTAL; }
-  __device__ __forceinline__ void boundary(int c, int lane) {
-    ring_pos = (ring_pos + 1) & (STAGES - 1);
-#if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-#else
-    if (DPW == 8) {           // 4-wave workgroups: 8 DMAs per wave per chunk, two younger chunks stay in flight
-      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else {
-    // This chunk's DMAs were issued three boundaries ago; the LOADS younger than them are the 8 DMAs of the next two
-    // chunks.  Loads (LDS-DMA included) return in issue order among themselves, so vmcnt(8) cannot pass while one of this
-    // chunk's DMAs is pending (then all 8 younger ones are too).  Stores share the counter but complete out of order with
-    // respect to loads: they may NOT be counted among the operations allowed to stay in flight (a store that completes
-    // early would let the wait pass too soon); pending stores simply count against the 8.  Loads the compiler issues
-    // itself only make the true count larger, so this never under-waits.
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-#endif
-#if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
-    if (spread(c)) issue_one((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), 0);
-    else issue((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1));
-#endif
-    woff = ring_pos * STAGE_BYTES + 16 * lane;
-  }
-  // fetch the group that starts at fragment fn (fn % RING_GROUP == 0) into nxt; crossing into a new chunk first
-  // runs the ring protocol for it (the previous chunk's last group is already in registers)
-  __device__ __forceinline__ void prefetch(int fn, int lane) {
-    if ((fn % CHUNK) == 0) boundary(fn / CHUNK, lane);
-#if NERF_ABLATE != 2
-    else if ((fn % (CHUNK / DPW)) == 0 && spread(fn / CHUNK))
-      issue_one((fn / CHUNK + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1),
-                (fn % CHUNK) / (CHUNK / DPW));
-#endif
-#pragma unroll
-    for (int i = 0; i < RING_GROUP; ++i)
-      nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % CHUNK) * 1024);
-  }
-  __device__ __forceinline__ void note_stores(int) {}
-  __device__ __forceinline__ void new_pass() {
-    // the ~1200 chunk/fragment source addresses are loop-invariant; hoisted, they no longer fit the SGPR file and
-    // are parked in VGPR lanes (v_writelane / v_readlane per DMA).  Opaque base per pass: two s_add per DMA instead.
-    asm volatile("" : "+s"(wsrc));
-  }
-  __device__ __forceinline__ void start(int lane) {
-    ring_pos = STAGES - 1;
-    woff = 0;
-#pragma unroll
-    for (int c = 0; c < STAGES - 1; ++c) issue(c, c);
-    prefetch(0, lane);
-  }
-  __device__ __forceinline__ bf16x8 frag(int f, int lane) {
-    if ((f % RING_GROUP) == 0) {
-#pragma unroll
-      for (int i = 0; i < RING_GROUP; ++i) cur[i] = nxt[i];
-      prefetch((f + RING_GROUP) % TOTAL, lane);           // wraps to the next pass over the weights
-      __builtin_amdgcn_sched_barrier(0);                  // keep hipcc from hoisting further groups (spills)
-    }
-    return cur[f % RING_GROUP];
-  }
-  __device__ __forceinline__ float4 bias4(int slot) {
-    return *reinterpret_cast<const float4*>(ring_smem + BIAS_OFF + slot * 4);
-  }
-  __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-};
-
-template <class WS> struct is_ring { static constexpr bool value = false; };
-template <int N, int T, int G, int W, int C, int S> struct is_ring<RingW<N, T, G, W, C, S>> { static constexpr bool value = true; };
-
-template <class WS>
-__device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }
-
+// weight sources (GlobalW: L1, RingW: LDS ring fed by LDS-DMA), FwdArgs, PeFreq: mlp_ring.h
 // ------------------------------------------------------------------------------------------
 // one linear layer on register-resident activations
 // ------------------------------------------------------------------------------------------
@@ -539,19 +339,6 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
   for (int t = 0; t < ST; ++t) { sink.put(t, 2 * NT - 2, out[t][2 * NT - 2]); sink.put(t, 2 * NT - 1, out[t][2 * NT - 1]); }
 }
 
-struct FwdArgs {
-  const bf16x8* wf;      // forward fragment stream
-  const float* bias;     // bias slots
-  const float* x;        // MODE 0: [M,90]
-  const float* rays;     // MODE 1: [B,11]
-  const float* z;        // MODE 1: [B,n]
-  int64_t M;
-  int n;
-  PeFreq fr;
-  float* out;            // [M,4]
-  void* acts;            // training store or nullptr
-  int64_t astride;       // 16-byte units between sample tiles of the activation store
-};
 
 // All 12 layers for ST sample tiles of this wave (tile0 .. tile0+ST-1).  Tiles >= ntiles are computed on clamped
 // inputs and never stored, so every wave runs the same instruction stream (the ring needs that).
@@ -712,10 +499,6 @@ __global__ void __launch_bounds__(256, (ST == 1 ? 2 : 1)) mlp_fwd_kernel(FwdArgs
   fwd_tiles<ST, MODE, STORE>(a, ws, tile0, ntiles, lane);
 }
 
-__device__ __forceinline__ void ring_load_bias(const float* __restrict__ bias, int count, int bias_off = RING_BIAS_OFF) {
-  for (int i = threadIdx.x; i < count; i += blockDim.x)
-    *reinterpret_cast<float*>(ring_smem + bias_off + 4 * i) = bias[i];
-}
 
 // variant 3: persistent workgroups of 8 waves x 32 samples, weights through the shared LDS ring
 constexpr int F_CHUNKS = L::F_TOTAL / RING_CHUNK;     // 37
@@ -777,62 +560,7 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_ring_kernel(FwdArgs a) {
 // Accumulator: col = lane&15 (sample), row = 4 (lane>>4) + reg; two stacked 16-feature tiles give the next layer's
 // B fragment, element j of lane group g = feature 16 (j>>2) + 4 g + (j&3) of the 32-feature k-step.
 // ==========================================================================================
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-namespace L16 {
-constexpr int F_L0 = 0, F_L1 = 32, F_L5 = 544, F_L6 = 704, F_L7 = 832, F_FA = 960, F_DIR = 1096, F_RGB = 1168;
-constexpr int CHUNKS = L::F16_PADDED / RING_CHUNK;     // 37
-}
-__host__ __device__ constexpr int kperm16(int ks, int g, int j) { return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3); }
-// Which embedding channel sits in element j of lane group g in the encoding k-steps.  The order is ours to choose
-// (the packed weights follow it), so it is chosen to make the per-element (sin | cos, x | y | z) pattern the same in
-// all four lane groups -- only the frequency differs, three per-lane registers -- instead of a table lookup and four
-// selects per element.  Position (63 channels, 2 k-steps = slots 8 ks + j): slots 0-11 = bands 2g, 2g+1 as
-// (sin xyz, cos xyz); slots 12-14 = band 8 + (g>>1), sin for even g / cos for odd g, xyz; slot 15 = identity
-// channel g (zero pad for g = 3).  Direction (27 channels, 1 k-step): j 0-5 = band g, j 6 = identity g, j 7 = pad.
-__host__ __device__ constexpr int pos_chan16(int ks, int g, int j) {
-  const int sl = 8 * ks + j;
-  if (sl < 12) return 3 + 6 * (2 * g + sl / 6) + (sl % 6);
-  if (sl < 15) return 3 + 6 * (8 + (g >> 1)) + 3 * (g & 1) + (sl - 12);
-  return g < 3 ? g : -1;
-}
-__host__ __device__ constexpr int dir_chan16(int g, int j) {
-  if (j < 6) return 3 + 6 * g + j;
-  return (j == 6 && g < 3) ? g : -1;
-}
-
-__device__ float fwd_src16(const float* __restrict__ p, int f, int i, int g, int j) {
-  if (f < L16::F_L1) {
-    const int nt = f / 2, ch = pos_chan16(f % 2, g, j);
-    return ch >= 0 ? p[L::P_W0 + (16 * nt + i) * 63 + ch] : 0.0f;
-  }
-  if (f < L16::F_L5) {
-    const int q = f - L16::F_L1, l = 1 + q / 128, r = q % 128;
-    return p[L::pw(l) + (16 * (r / 8) + i) * 256 + kperm16(r % 8, g, j)];
-  }
-  if (f < L16::F_L6) {
-    const int q = f - L16::F_L5, n = 16 * (q / 10) + i, ks = q % 10;
-    if (ks < 2) { const int ch = pos_chan16(ks, g, j); return ch >= 0 ? p[L::P_W5 + n * 319 + ch] : 0.0f; }
-    return p[L::P_W5 + n * 319 + 63 + kperm16(ks - 2, g, j)];
-  }
-  if (f < L16::F_FA) {
-    const int q = f - L16::F_L6, l = 6 + q / 128, r = q % 128;
-    return p[L::pw(l) + (16 * (r / 8) + i) * 256 + kperm16(r % 8, g, j)];
-  }
-  if (f < L16::F_DIR) {
-    const int q = f - L16::F_FA;
-    if (q < 128) return p[L::P_WF + (16 * (q / 8) + i) * 256 + kperm16(q % 8, g, j)];
-    return i == 0 ? p[L::P_WA + kperm16(q - 128, g, j)] : 0.0f;
-  }
-  if (f < L16::F_RGB) {
-    const int q = f - L16::F_DIR, n = 16 * (q / 9) + i, ks = q % 9;
-    if (ks < 8) return p[L::P_WD + n * 283 + kperm16(ks, g, j)];
-    const int ch = dir_chan16(g, j);
-    return ch >= 0 ? p[L::P_WD + n * 283 + 256 + ch] : 0.0f;
-  }
-  if (f < L::F16_TOTAL) return i < 3 ? p[L::P_WR + i * 128 + kperm16(f - L16::F_RGB, g, j)] : 0.0f;
-  return 0.0f;
-}
-
+// L16 stream offsets, kperm16, pos_chan16 / dir_chan16, fwd_src16: mlp_layout.h
 // the whole bf16 image in ONE launch (was two: at N_rand = 1024 the ~30 five-microsecond launches of an iteration are a tenth
 // of it): blocks [0, PACK_BLOCKS) build the 32x32x16 forward / backward streams and the bias slots, the rest the 16x16x32
 // forward stream of the render kernels
@@ -2043,7 +1771,10 @@ static int g_ring_split = 1;     // training ring kernels: 1 = one 8-wave workgr
 // precision of a model = nerf_mlp_arch.precision (ABI 3): 16 (or 0) bf16 MFMA operands with fp32 accumulate, 32 the fp32
 // reference-precision kernels of mlp32.hip.  Nothing process-wide: two models of different precision can be packed,
 // queried and trained side by side on any streams.
-static inline int arch_prec(const nerf_mlp_arch* a) { return a->precision == 32 ? 32 : 16; }
+// 22 = split-fp16 inference (mlp22.hip: float32-class accuracy at 1/3 of the fp16 matrix rate) over the fp32 kernels for
+// everything that keeps activations (training forward, backward): such a model carries all three weight images.
+static inline int arch_prec(const nerf_mlp_arch* a) { return a->precision == 32 ? 32 : a->precision == 22 ? 22 : 16; }
+static inline bool arch_f32(const nerf_mlp_arch* a) { return a->precision == 32 || a->precision == 22; }   // trains on mlp32.hip
 // CUs of the current device (256 on an MI355X in SPX mode), asked once: the persistent kernels and the dW split are
 // sized to it instead of to a constant
 // Per-device state: the CU count and the "dynamic LDS attribute set" flags belong to the CURRENT device (a process may
@@ -2078,8 +1809,8 @@ static void ensure_lds(K kernel, int bytes) {
 // model (32+16 -> 4, 2 x 64), -1: no HIP kernel
 static int arch_kind(const nerf_mlp_arch* a) {
   if (!a) return -1;
-  if (a->precision != 0 && a->precision != 16 && a->precision != 32) return -1;
-  if (a->precision == 32 && !(a->n_layers == 8 && a->width == 256 && a->use_viewdirs == 1)) return -1;   // fp32 kernels: 8 x 256 view model only
+  if (a->precision != 0 && a->precision != 16 && a->precision != 32 && a->precision != 22) return -1;
+  if (arch_f32(a) && !(a->n_layers == 8 && a->width == 256 && a->use_viewdirs == 1)) return -1;   // fp32 / split-fp16 kernels: 8 x 256 view model only
   if (a->n_layers == 2 && a->width == 64 && a->skip_layer < 0 && a->use_viewdirs == 1 && a->in_pos == 32 && a->in_dir == 16) return 2;
   if (a->n_layers != 8 || a->width != 256 || a->skip_layer != 4) return -1;
   if (a->use_viewdirs == 1 && a->in_pos == 63 && a->in_dir == 27) return 0;
@@ -2136,22 +1867,24 @@ extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) {
 extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
   // an fp32 (precision 32) 8 x 256 view model carries its fp32 streams behind the bf16 image
-  return k == 0 ? L::PACKED_BYTES + (arch_prec(arch) == 32 ? f32::PACKED_BYTES : 0) : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
+  // ... and a precision-22 model its split-fp16 stream behind that
+  return k == 0 ? L::PACKED_BYTES + (arch_f32(arch) ? f32::PACKED_BYTES : 0) + (arch_prec(arch) == 22 ? f22::PACKED_BYTES : 0) : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
 }
 static inline const void* packed32_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES; }
+static inline const void* packed22_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES + f32::PACKED_BYTES; }
 static inline int64_t padded_tiles(int64_t M) { return (((M + 31) / 32) + 7) / 8 * 8; }
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
   const int64_t b16 = padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16() : small_astride16()) * 16;
-  return (k == 0 && arch_prec(arch) == 32) ? f32::acts_bytes(M) : b16;
+  return (k == 0 && arch_f32(arch)) ? f32::acts_bytes(M) : b16;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
   const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16
                       + DW_PARTIAL_BYTES;                 // + the split-K partial tiles of the weight-gradient kernel
-  return (k == 0 && arch_prec(arch) == 32) ? f32::dz_bytes(M) : b16;
+  return (k == 0 && arch_f32(arch)) ? f32::dz_bytes(M) : b16;
 }
 
 #define NERF_ARCH_MSG ": HIP kernels exist for (8x256, skip 4) with in=63+27 view head, or in=40 / no view head / out_ch<=4, and for (2x64, no skip) with in=32+16 view head"
@@ -2185,7 +1918,8 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
                      reinterpret_cast<bf16x8*>(base + L::F16_OFFSET));
   int rc = check_launch("nerf_mlp_pack");
   if (rc) return rc;
-  if (arch_prec(arch) == 32) rc = f32::pack(params, base + L::PACKED_BYTES, as_stream(stream));
+  if (arch_f32(arch)) rc = f32::pack(params, base + L::PACKED_BYTES, as_stream(stream));
+  if (!rc && arch_prec(arch) == 22) rc = f22::pack(params, base + L::PACKED_BYTES + f32::PACKED_BYTES, as_stream(stream));
   return rc;
 }
 
@@ -2300,7 +2034,9 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     return check_launch("mlp forward (image model)");
   }
-  if (arch_prec(arch) == 32) {
+  if (arch_prec(arch) == 22 && !acts)          // inference: split fp16 on the 16-bit matrix pipe
+    return f22::forward(packed22_of(packed), x, nullptr, nullptr, M, 1, 0, out, ring_wgs(), as_stream(stream));
+  if (arch_f32(arch)) {
     return f32::forward(packed32_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, as_stream(stream));
   }
   return launch_fwd<0>(packed, x, nullptr, nullptr, M, 1, 0, out, acts, stream);
@@ -2319,7 +2055,9 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   NERF_REQUIRE(packed && rays && z && raw, NERF_E_NULL, "nerf_query_fused: NULL pointer");
   NERF_REQUIRE(freq_mode == 0 || freq_mode == 1, NERF_E_UNSUPPORTED, "nerf_query_fused: freq_mode must be 0 or 1");
   NERF_REQUIRE(B * (int64_t)n < (1ll << 31), NERF_E_SHAPE, "nerf_query_fused: B*n must be < 2^31 samples per call");
-  if (arch_prec(arch) == 32) {
+  if (arch_prec(arch) == 22 && !acts)
+    return f22::forward(packed22_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, ring_wgs(), as_stream(stream));
+  if (arch_f32(arch)) {
     return f32::forward(packed32_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts, as_stream(stream));
   }
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
@@ -2445,7 +2183,7 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     jobi(LI::Z_OUT, 1, LI::A_H0 + 112, 16, LI::P_WO, 256, 0, arch->out_ch, 256, LI::P_WO + arch->out_ch * 256);   // output
     return launch_dw(di, nji, ntiles, img_params(arch), acts, dz, img_astride16(), img_zstride16(), grads, s);
   }
-  if (arch_prec(arch) == 32) {
+  if (arch_f32(arch)) {
     return f32::backward(packed32_of(packed), acts, d_raw, M, dz, grads, s);
   }
   // ---- 1. dZ chain
@@ -2576,7 +2314,7 @@ static bool debug_slot(int kind, int layer, int* slot, int* nfrag) {
 extern "C" int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int layer) {
   int slot = 0, nfrag = 0;
   if (!arch_ok(arch)) return -1;
-  if (arch_prec(arch) == 32) return f32::debug_width(kind, layer);
+  if (arch_f32(arch)) return f32::debug_width(kind, layer);
   if (!debug_slot(kind, layer, &slot, &nfrag)) return -1;
   return 16 * nfrag;
 }
@@ -2584,7 +2322,7 @@ extern "C" int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int lay
 extern "C" int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store, int kind, int layer, int64_t M,
                                    float* out, void* stream) {
   NERF_ARCH_CHECK("nerf_mlp_debug_read");
-  if (arch_prec(arch) == 32) {
+  if (arch_f32(arch)) {
     NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");
     return M <= 0 ? NERF_OK : f32::debug_read(store, kind, layer, M, out, as_stream(stream));
   }

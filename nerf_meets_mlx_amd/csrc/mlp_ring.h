@@ -1,0 +1,206 @@
+// Shared pieces of the fused-MLP kernels (mlp.hip: bf16 operands; mlp22.hip: split-fp16 operands): vector types,
+// LDS-DMA helpers, the LDS weight ring (RingW) and the argument block of the forward kernels.
+#pragma once
+#include "common.h"
+
+#ifndef NERF_SPREAD_DMA
+#define NERF_SPREAD_DMA 1     // ring refill: one DMA per quarter chunk interval instead of a burst of 4
+#endif
+#ifndef NERF_ABLATE
+#define NERF_ABLATE 0
+#endif
+// (Round 1 had a switch NERF_EXACT_VMCNT that counted the fragment stores of the last three chunk intervals into the ring's
+// vmcnt wait: no gain in the training forward, spills in the backward chain -- and, as the fp32 kernels showed in round 3,
+// WRONG in principle: stores complete out of order with respect to loads, so a wait may only count younger LOADS
+// (mlp32.hip, frag_wait_n).  Removed.)
+// A/B switches (both default on): non-temporal DMA loads in the dW kernel / non-temporal fragment stores
+#ifndef NERF_NT_DW_LOADS
+#define NERF_NT_DW_LOADS 1
+#endif
+
+namespace nerf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PeFreq { float pos[10]; float dir[4]; };
+
+// ------------------------------------------------------------------------------------------
+// weight sources: where a wave gets the 1 KiB A-operand fragment `f` of the packed stream from
+// ------------------------------------------------------------------------------------------
+// one 1 KiB fragment global -> LDS with no VGPR round trip (lane i lands at lds_addr + 16 i).
+// Inline asm on purpose: hipcc treats the builtin as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front
+// of the next ds_read of the same array, which drains the whole prefetch ring every tile.  Hidden in asm, the
+// DMAs are ordered by OUR counted `s_waitcnt vmcnt(N)` + s_barrier (cdna_hip_programming.md 5.7).  M0 carries
+// the LDS byte address and is restored because the compiler owns it.
+__device__ __forceinline__ void dma_frag(const void* gsrc_lane, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+}
+// same with a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (no 64-bit VGPR address per fragment,
+// which hipcc would otherwise hoist out of persistent loops and spill)
+__device__ __forceinline__ void dma_frag_s(const void* gbase_uniform, unsigned lane_off, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off), "s"(gbase_uniform), "s"(lds_addr) : "memory");
+}
+// non-temporal form for bytes that are read exactly once (the dW kernel's dZ / activation stream)
+__device__ __forceinline__ void dma_frag_nt(const void* gsrc_lane, unsigned lds_addr) {
+  unsigned keep;
+#if NERF_NT_DW_LOADS
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+#else
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
+#endif
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}
+
+// (1) straight from global memory / L1: no synchronisation between waves (variants 1 and 2)
+struct GlobalW {
+  const bf16x8* __restrict__ wlane;    // stream base + lane
+  const float* __restrict__ bias;
+  __device__ __forceinline__ bf16x8 frag(int f, int) { return wlane[f * 64]; }
+  __device__ __forceinline__ void note_stores(int) {}
+  __device__ __forceinline__ float4 bias4(int slot) { return *reinterpret_cast<const float4*>(bias + slot); }
+};
+
+// (2) LDS ring fed by LDS-DMA and shared by the 8 waves of a workgroup (variant 3).  The stream is consumed
+// strictly in order by every wave; chunk = 32 fragments (32 KiB), 4 stages, 3 chunks in flight.  At a chunk
+// boundary every wave: waits for ITS share of the chunk (counted vmcnt: the 2 younger chunks stay in flight),
+// barrier (everybody's share landed; everybody finished reading the previous chunk), then refills the stage that
+// just became free with the chunk 3 ahead (wrapping to the next pass over the weights).
+constexpr int RING_CHUNK = 32, RING_STAGES = 4, RING_STAGE_BYTES = RING_CHUNK * 1024;
+constexpr int RING_BIAS_OFF = RING_STAGES * RING_STAGE_BYTES;          // fp32 bias slots behind the ring
+constexpr int RING_LDS_BYTES = RING_BIAS_OFF + 2560 * 4;
+
+extern __shared__ __attribute__((aligned(16))) char ring_smem[];
+
+// RING_GROUP = fragments per software-pipeline group (one group in use, one in flight); TOTAL = fragments
+// consumed per pass (multiple of RING_GROUP)
+// CHUNK / STAGES: fragments per ring stage and stages (default 32 x 4 = 128 KiB for one 8-wave workgroup per CU; 16 x 4 =
+// 64 KiB lets two independent 4-wave workgroups share a CU, see mlp_fwd_ring_kernel)
+template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES>
+struct RingW {
+  static constexpr int DPW = CHUNK / NW;               // DMAs per wave per chunk
+  static constexpr int STAGE_BYTES = CHUNK * 1024, BIAS_OFF = STAGES * STAGE_BYTES, LDS_BYTES = BIAS_OFF + 2560 * 4;
+  static_assert(DPW * NW == CHUNK && (DPW == 4 || DPW == 8), "ring: 4 or 8 DMAs per wave per chunk");
+  const char* __restrict__ wsrc;       // global stream base (uniform)
+  unsigned lane16;                     // 16 * lane
+  unsigned lds0;                       // LDS byte address of ring_smem (M0 values are absolute)
+  int wv;                              // wave id in the workgroup (uniform)
+  int ring_pos;                        // stage of the chunk the prefetch reads from
+  int woff;                            // ring_pos * STAGE + 16 * lane
+  bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
+
+  // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k
+  __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
+    const int i = wv + NW * k;
+    dma_frag_s(wsrc + ((int64_t)chunk * CHUNK + i) * 1024, lane16, lds0 + stage * STAGE_BYTES + i * 1024);
+  }
+  __device__ __forceinline__ void issue(int chunk, int stage) {
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) issue_one(chunk, stage, k);
+  }
+  // Whole chunks refill their freed stage one DMA per quarter of the interval (a burst of 4 right behind the barrier
+  // stalls both waves of a SIMD on the VMEM issue path at once); the partial last chunk of a pass keeps the burst.
+  // (not in the activation-storing training forward, RING_GROUP 2: it is at the VGPR limit and HBM-bound anyway)
+  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && RING_GROUP == 4 && (c + 1) * CHUNK <= TOTAL; }
+  __device__ __forceinline__ void boundary(int c, int lane) {
+    ring_pos = (ring_pos + 1) & (STAGES - 1);
+#if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#else
+    if (DPW == 8) {           // 4-wave workgroups: 8 DMAs per wave per chunk, two younger chunks stay in flight
+      asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+    // This chunk's DMAs were issued three boundaries ago; the LOADS younger than them are the 8 DMAs of the next two
+    // chunks.  Loads (LDS-DMA included) return in issue order among themselves, so vmcnt(8) cannot pass while one of this
+    // chunk's DMAs is pending (then all 8 younger ones are too).  Stores share the counter but complete out of order with
+    // respect to loads: they may NOT be counted among the operations allowed to stay in flight (a store that completes
+    // early would let the wait pass too soon); pending stores simply count against the 8.  Loads the compiler issues
+    // itself only make the true count larger, so this never under-waits.
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#endif
+#if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
+    if (spread(c)) issue_one((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), 0);
+    else issue((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1));
+#endif
+    woff = ring_pos * STAGE_BYTES + 16 * lane;
+  }
+  // fetch the group that starts at fragment fn (fn % RING_GROUP == 0) into nxt; crossing into a new chunk first
+  // runs the ring protocol for it (the previous chunk's last group is already in registers)
+  __device__ __forceinline__ void prefetch(int fn, int lane) {
+    if ((fn % CHUNK) == 0) boundary(fn / CHUNK, lane);
+#if NERF_ABLATE != 2
+    else if ((fn % (CHUNK / DPW)) == 0 && spread(fn / CHUNK))
+      issue_one((fn / CHUNK + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1),
+                (fn % CHUNK) / (CHUNK / DPW));
+#endif
+#pragma unroll
+    for (int i = 0; i < RING_GROUP; ++i)
+      nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % CHUNK) * 1024);
+  }
+  __device__ __forceinline__ void note_stores(int) {}
+  __device__ __forceinline__ void new_pass() {
+    // the ~1200 chunk/fragment source addresses are loop-invariant; hoisted, they no longer fit the SGPR file and
+    // are parked in VGPR lanes (v_writelane / v_readlane per DMA).  Opaque base per pass: two s_add per DMA instead.
+    asm volatile("" : "+s"(wsrc));
+  }
+  __device__ __forceinline__ void start(int lane) {
+    ring_pos = STAGES - 1;
+    woff = 0;
+#pragma unroll
+    for (int c = 0; c < STAGES - 1; ++c) issue(c, c);
+    prefetch(0, lane);
+  }
+  __device__ __forceinline__ bf16x8 frag(int f, int lane) {
+    if ((f % RING_GROUP) == 0) {
+#pragma unroll
+      for (int i = 0; i < RING_GROUP; ++i) cur[i] = nxt[i];
+      prefetch((f + RING_GROUP) % TOTAL, lane);           // wraps to the next pass over the weights
+      __builtin_amdgcn_sched_barrier(0);                  // keep hipcc from hoisting further groups (spills)
+    }
+    return cur[f % RING_GROUP];
+  }
+  __device__ __forceinline__ float4 bias4(int slot) {
+    return *reinterpret_cast<const float4*>(ring_smem + BIAS_OFF + slot * 4);
+  }
+  __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+template <class WS> struct is_ring { static constexpr bool value = false; };
+template <int N, int T, int G, int W, int C, int S> struct is_ring<RingW<N, T, G, W, C, S>> { static constexpr bool value = true; };
+
+template <class WS>
+__device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }
+
+
+struct FwdArgs {
+  const bf16x8* wf;      // forward fragment stream
+  const float* bias;     // bias slots
+  const float* x;        // MODE 0: [M,90]
+  const float* rays;     // MODE 1: [B,11]
+  const float* z;        // MODE 1: [B,n]
+  int64_t M;
+  int n;
+  PeFreq fr;
+  float* out;            // [M,4]
+  void* acts;            // training store or nullptr
+  int64_t astride;       // 16-byte units between sample tiles of the activation store
+};
+
+__device__ __forceinline__ void ring_load_bias(const float* __restrict__ bias, int count, int bias_off = RING_BIAS_OFF) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x)
+    *reinterpret_cast<float*>(ring_smem + bias_off + 4 * i) = bias[i];
+}
+
+}  // namespace nerf

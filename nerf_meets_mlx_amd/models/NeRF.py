@@ -36,7 +36,9 @@ class NeRF:
     """Same constructor arguments as `mlx_nerf/models/NeRF.py:160-199`.  Initialisation is
     mlx.nn.Linear's: weight and bias ~ U(-1/sqrt(in), 1/sqrt(in)) (seeded numpy stream).
     precision (ours): 16 = bf16 MFMA operands with fp32 accumulate (the benchmarked mode), 32 = the reference's own
-    float32 arithmetic on the fp32 MFMA (8 x 256 view model only).  It is part of the model (`nerf_mlp_arch.precision`):
+    float32 arithmetic on the fp32 MFMA (8 x 256 view model only), 22 = the same for everything that trains, and the
+    split-fp16 kernel (csrc/mlp22.hip: float32 operands as hi + lo fp16 pairs, three fp16 MFMAs per product, float32-class
+    accuracy at ~4 x the fp32 MFMA's speed) for inference.  It is part of the model (`nerf_mlp_arch.precision`):
     weight image, workspaces and every launch of this object use it; models of both kinds can be used side by side."""
 
     def __init__(self, n_layers=8, width_layers=256, channel_input=3, channel_input_views=3, channel_output=4,
@@ -53,8 +55,9 @@ class NeRF:
         self.arch = N.MlpArch(n_layers, width_layers, channel_input, channel_input_views,
                               self.list_skip_connection_layers[0] if len(self.list_skip_connection_layers) == 1 else -1,
                               int(bool(is_use_view_directions)), channel_output, int(precision))
-        if precision not in (16, 32):
-            raise ValueError("NeRF: precision must be 16 (bf16 MFMA operands) or 32 (fp32 MFMA)")
+        if precision not in (16, 22, 32):
+            raise ValueError("NeRF: precision must be 16 (bf16 MFMA operands), 32 (fp32 MFMA) or 22 (fp32 MFMA for training, "
+                             "split-fp16 MFMA at float32 tolerance for inference)")
         self.precision = int(precision)
         self.out_dim = 4 if is_use_view_directions else channel_output
         rng = np.random.default_rng(seed)
