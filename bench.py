@@ -11,6 +11,12 @@ sampling + fine) on the synthetic Lego-like 800x800 scene (BASELINE.json configs
 resident in HBM before the timed region.  value = (train rays + render rays) of ALL ranks / time;
 rays shard across ranks with no data-path collective except the gradient all-reduce (weak scaling).
 
+The headline step runs at `--precision 22`: the reference's float32 TOLERANCE on the 16-bit matrix pipe (every float32 GEMM
+operand as a hi + lo pair of 16-bit numbers, three MFMAs per product, fp32 accumulate: csrc/mlp_s16.hip for training,
+csrc/mlp22.hip for rendering), held to the same fixture tolerances as the float32 kernels.  The N = 1 line also carries the
+same step with literal float32 operands on the fp32 MFMA (`fp32`, `reference_precision_value`) and in the declared
+reduced-precision bf16 mode (`bf16`).
+
 The JSON line also carries `roofline` for the dominant kernel (the fused MLP forward of the render
 fine pass, MFMA-bound, timed with events on the launch stream inside the timed region) and
 `cpu_baseline` (the CPU oracle = op-for-op restatement of the reference, timed on this box's host
@@ -32,7 +38,14 @@ if ROOT not in sys.path:
 FLOP_PER_SAMPLE_FWD = 2 * 593408          # SURVEY 8d / BASELINE.md section 2
 BF16_MFMA_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16 MFMA
 FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
-TRAIN_BYTES_PER_SAMPLE = (321 + 356 + 9) * 1024 / 32      # HBM bytes per sample of a training pass (8 TB/s peak)
+# HBM bytes per sample of a training pass (8 TB/s peak): fragment blocks written once by forward / chain and read once by
+# the weight-gradient jobs + sign-bit words (bf16: DESIGN 4.2; split bf16: hi + lo blocks of everything + the re-read encodings;
+# fp32: [tile][row][32] float rows)
+TRAIN_BYTES = {16: (321 + 356 + 9) * 1024 / 32, 22: (633 + 712 + 9 + 12) * 1024 / 32, 32: (2592 + 2496) * 128 * 2 / 32}
+PEAK_TFLOPS = {16: BF16_MFMA_PEAK_TFLOPS, 22: BF16_MFMA_PEAK_TFLOPS / 3.0, 32: FP32_MFMA_PEAK_TFLOPS}
+KERNEL = {16: "mlp_fwd_ring16_kernel<8,2>", 22: "mlp22_fwd_kernel<1>", 32: "mlp32_fwd_kernel"}
+DTYPE = {16: "bf16", 22: "f32 (split 16-bit MFMA operands: fp16 hi+lo render, bf16 hi+lo training; fp32 accumulate)", 32: "f32"}
+DTYPE_SHORT = {16: "bf16", 22: "f32_split16", 32: "f32"}
 
 
 def main():
@@ -51,6 +64,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="time box of the cpu_baseline render leg (the training leg runs "
                     "its 20 steps of SURVEY 8(d) whatever they take, capped at --cpu-train-cap seconds)")
     ap.add_argument("--cpu-train-cap", type=float, default=600.0, help="safety cap of the cpu_baseline training leg")
+    ap.add_argument("--precision", type=int, default=22, choices=[16, 22, 32],
+                    help="precision of the headline step: 22 = the reference's float32 tolerance on the 16-bit matrix pipe (default), "
+                         "16 = bf16 operands (declared reduced precision), 32 = float32 operands on the fp32 MFMA")
     ap.add_argument("--mlp-variant", type=int, default=0)
     ap.add_argument("--n-importance", type=int, default=128, help="0 = coarse-only (BASELINE configs[1] with --hw 400)")
     ap.add_argument("--config", choices=["nerf", "ngp"], default="nerf",
@@ -190,25 +206,45 @@ def main():
                 "rays_per_s": H * W / dt, "chunks": (H * W + 32767) // 32768,
                 "outputs": ["rgb_map", "disp_map", "acc_map"] + sorted(extras.keys())}
 
-    m = measure(16, args.steps, args.warmup)                       # THE timed region of the contract
-    dt, value, k_ms, t_train, t_render = m["dt"], m["value"], m["k_ms"], m["t_train"], m["t_render"]
+    HP = args.precision                                            # precision of the headline step (default 22)
+    m = measure(HP, args.steps, args.warmup)                       # THE timed region of the contract
+    dt, value = m["dt"], m["value"]
     # dominant kernel: fused MLP forward over render_rays x 192 samples
     flop = FLOP_PER_SAMPLE_FWD * args.render_rays * n_fine
-    # per-phase throughput (events on the launch stream) and algorithmic MFMA fractions (train = 3x forward
-    # FLOPs over 64 + n_fine samples, render = 1x; the repeated coarse forward of __test_nerf.py:270 is not credited)
-    train_tf = 3 * FLOP_PER_SAMPLE_FWD * spr * args.n_rand / t_train / 1e12
-    render_tf = FLOP_PER_SAMPLE_FWD * spr * args.render_rays / t_render / 1e12
-    achieved = flop / (k_ms * 1e-3) / 1e12
+
+    def derived(mm, prec, n_rand):
+        """per-phase throughput (events on the launch stream) and algorithmic MFMA fractions (train = 3x forward
+        FLOPs over 64 + n_fine samples, render = 1x; the repeated coarse forward of __test_nerf.py:270 is not credited)
+        against the matrix peak of the precision: 16 -> dense bf16; 32 -> fp32 MFMA; 22 -> THREE 16-bit MFMAs per float32
+        product, i.e. a third of the dense 16-bit peak in algorithmic FLOPs (executed matrix FLOPs = 3 x algorithmic)."""
+        pk = PEAK_TFLOPS[prec]
+        a = flop / (mm["k_ms"] * 1e-3) / 1e12
+        d = {"value": mm["value"], "unit": "rays/s", "steps": mm["steps"], "ms_per_step": mm["ms_per_step"],
+             "train_rays_per_s": n_rand / mm["t_train"], "render_rays_per_s": args.render_rays / mm["t_render"],
+             "train_mfma_frac": 3 * FLOP_PER_SAMPLE_FWD * spr * n_rand / mm["t_train"] / 1e12 / pk,
+             "render_mfma_frac": FLOP_PER_SAMPLE_FWD * spr * args.render_rays / mm["t_render"] / 1e12 / pk,
+             "train_hbm_frac": TRAIN_BYTES[prec] * spr * n_rand / mm["t_train"] / 8e12,
+             "loss_coarse": mm["loss_coarse"], "loss_fine": mm["loss_fine"], "dtype": DTYPE[prec],
+             "roofline": {"bound": "mfma", "kernel": KERNEL[prec] + " (render fine pass)", "achieved": a, "peak": pk,
+                          "unit": "TFLOP/s", "frac": a / pk, "ms_per_launch": mm["k_ms"],
+                          "samples_per_launch": args.render_rays * n_fine}}
+        if prec == 22:
+            d["roofline"]["executed_mfma_tflops"] = 3 * a
+            d["roofline"]["peak_note"] = ("algorithmic float32 FLOPs against 2500 / 3 TFLOP/s: every float32 product is three "
+                                          "v_mfma_f32_16x16x32_f16 (hi hi + hi lo + lo hi) of the 2500 TFLOP/s dense 16-bit pipe")
+        return d
+
+    hd = derived(m, HP, args.n_rand)
     # HBM bytes per launch of that kernel: NOT measured by this run -- taken from the newest committed PMC passes of this
-    # same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh) when their
-    # samples-per-launch matches this workload; labelled as cached in the line.  null otherwise.
+    # same command (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh) when their kernel and
+    # samples-per-launch match this workload; labelled as cached in the line.  null otherwise.
     traffic, traffic_src = None, None
     tpath = _latest_profile("r0*_pmc_traffic.json")
     if tpath:
         try:
             with open(tpath) as fp:
                 pm = json.load(fp)
-            if pm.get("samples_per_launch") == args.render_rays * n_fine:
+            if pm.get("samples_per_launch") == args.render_rays * n_fine and KERNEL[HP].split("<")[0] in pm.get("kernel", ""):
                 traffic = pm["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{os.path.basename(tpath)} (cached PMC run of this command, not this run; " + pm.get("note", "FETCH_SIZE + WRITE_SIZE") + ")"
         except (OSError, ValueError, KeyError):
@@ -217,79 +253,80 @@ def main():
     busy, busy_src = None, None
     bpath = _latest_profile("r0*_pmc_mfma_lds.csv")
     if bpath and args.mlp_variant in (0, 4) and NI == 128 and args.render_rays == 32768:
-        busy = _read_pmc_busy(bpath, "mlp_fwd_ring16_kernel<8,2>")
+        busy = _read_pmc_busy(bpath, KERNEL[HP])
         busy_src = f"profiles/{os.path.basename(bpath)} (cached PMC run)" if busy is not None else None
+    mode_text = {
+        22: "HEADLINE `value` = the REFERENCE-TOLERANCE mode on the 16-bit matrix pipe (precision 22): every float32 GEMM operand "
+            "as a (hi, lo) pair of 16-bit numbers, three MFMAs per float32 product, fp32 accumulate -- split-bf16 training "
+            "(csrc/mlp_s16.hip), split-fp16 rendering (csrc/mlp22.hip); held to the SAME fixture tolerances as the float32 "
+            "kernels (1e-4 of the output scale vs the reference's own outputs; measured 1e-5 training / 2e-6 rendering).  The "
+            "same step with literal float32 operands on the fp32 MFMA is `reference_precision_value`, the declared "
+            "reduced-precision bf16 mode is the `bf16` leg (N = 1 line)",
+        16: "HEADLINE `value` = the DECLARED REDUCED-PRECISION MODE (bf16 MFMA operands, fp32 accumulate; the reference computes "
+            "in float32)",
+        32: "HEADLINE `value` = the reference's float32 arithmetic on the fp32 MFMA"}[HP]
     line = {
         "metric": f"train+render rays/sec on Lego {H}x{W} (synthetic), " + (f"coarse+fine 64+{NI}" if NI > 0 else "coarse-only 64"),
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": DTYPE[HP], "data": "synthetic",
         "config": {"workload": (f"configs[2]: Lego {H}x{W} coarse+fine NeRF (64+{NI} importance samples), " if NI > 0 else
                                 f"configs[1]: Lego {H}x{W} coarse-only NeRF (64 samples/ray), ")
-                               + f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU; "
-                               "HEADLINE `value` = the DECLARED REDUCED-PRECISION MODE (bf16 MFMA operands, fp32 accumulate; the "
-                               "reference computes in float32) -- the same step at the reference's float32 arithmetic is "
-                               "`reference_precision_value` (N = 1 line)",
-                   "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
+                               + f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU; " + mode_text,
+                   "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}",
+                   "precision": HP},
         "comm_ms_per_step": m["comm_ms_per_step"],
-        "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
-        "train_mfma_frac": train_tf / BF16_MFMA_PEAK_TFLOPS, "render_mfma_frac": render_tf / BF16_MFMA_PEAK_TFLOPS,
-        # the training phase against its other roofline: bf16 activations + dZ written once (321 KiB per 32-sample tile)
-        # and read once by the weight-gradient jobs (356 KiB) + sign-bit words (9 KiB) = 21.4 KB per sample
-        "train_hbm_frac": TRAIN_BYTES_PER_SAMPLE * spr * args.n_rand / t_train / 8e12,
+        "train_rays_per_s_per_gpu": hd["train_rays_per_s"], "render_rays_per_s_per_gpu": hd["render_rays_per_s"],
+        "train_mfma_frac": hd["train_mfma_frac"], "render_mfma_frac": hd["render_mfma_frac"],
+        # the training phase against its other roofline: activations + dZ written once and read once by the weight-gradient
+        # jobs + sign-bit words (bf16: 21.4 KB per sample; split bf16: hi + lo blocks, 42.7 KB)
+        "train_hbm_frac": hd["train_hbm_frac"],
         "loss_coarse": m["loss_coarse"], "loss_fine": m["loss_fine"],
-        "roofline": {"bound": "mfma", "kernel": ("mlp_fwd_ring16_kernel<8,2>" if args.mlp_variant in (0, 4) else f"fused MLP forward, mlp_variant {args.mlp_variant}") + " (render fine pass)", "achieved": achieved,
-                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "traffic_source": traffic_src,
-                     "mfma_busy_cycles_frac": busy, "mfma_busy_source": busy_src, "algorithmic_bytes": args.render_rays * (n_fine * 20 + 44),
-                     "ms_per_launch": k_ms, "samples_per_launch": args.render_rays * n_fine},
+        "roofline": dict(hd["roofline"], traffic=traffic, traffic_unit="bytes/launch (PMC)", traffic_source=traffic_src,
+                         mfma_busy_cycles_frac=busy, mfma_busy_source=busy_src,
+                         algorithmic_bytes=args.render_rays * (n_fine * 20 + 44)),
     }
     if world == 1 and not args.no_extra_legs:
-        # ---- sustained: the same bf16 step for >= args.sustain_seconds (the burst above is < 1 s of a power-limited
+        # ---- sustained: the same headline step for >= args.sustain_seconds (the burst above is ~2 s of a power-limited
         # kernel; this is what the chip holds, and long enough for an SMI sampler to see the GPU busy)
         n_sus = max(args.steps, int(np.ceil(args.sustain_seconds * 1.05 / (dt / args.steps))))
-        ms = measure(16, n_sus, 2)
+        ms = measure(HP, n_sus, 2)
         if ms["dt"] < args.sustain_seconds:                      # the burst's step time underestimated it (first-run effects): once more, scaled
             n_sus = int(np.ceil(n_sus * args.sustain_seconds * 1.1 / ms["dt"]))
-            ms = measure(16, n_sus, 2)
+            ms = measure(HP, n_sus, 2)
         ms.pop("trainer", None)
         line["sustained"] = {"seconds": ms["dt"], "steps": n_sus, "value": ms["value"], "unit": "rays/s",
                              "ms_per_step": ms["ms_per_step"], "ms_per_launch": ms["k_ms"],
-                             "roofline_frac": flop / (ms["k_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                             "roofline_frac": flop / (ms["k_ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[HP],
                              "train_rays_per_s": args.n_rand / ms["t_train"], "render_rays_per_s": args.render_rays / ms["t_render"],
-                             "ratio_to_burst": ms["value"] / value, "dtype": "bf16"}
+                             "ratio_to_burst": ms["value"] / value, "dtype": DTYPE[HP]}
         # ---- lego.txt's batch: the reference's configs/lego.txt trains with N_rand = 1024 (the headline uses the argparse
         # default 4096, config_parser.py:17); same step, launch overheads weigh more
         if args.n_rand != 1024:
-            ml = measure(16, args.steps, args.warmup, n_rand=1024)
+            ml = measure(HP, args.steps, args.warmup, n_rand=1024)
             ml.pop("trainer", None)
-            line["lego_batch"] = {"n_rand_per_gpu": 1024, "value": ml["value"], "unit": "rays/s", "steps": ml["steps"],
-                                  "ms_per_step": ml["ms_per_step"], "train_rays_per_s": 1024 / ml["t_train"],
-                                  "render_rays_per_s": args.render_rays / ml["t_render"],
-                                  "train_mfma_frac": 3 * FLOP_PER_SAMPLE_FWD * spr * 1024 / ml["t_train"] / 1e12 / BF16_MFMA_PEAK_TFLOPS}
-        # ---- fp32: the same step at the REFERENCE's arithmetic (models/NeRF.py:201-243 runs in MLX float32):
-        # Trainer(precision=32) -> float32 operands on v_mfma_f32_32x32x2_f32, against the fp32 matrix peak
-        m32 = measure(32, args.fp32_steps, 2)
-        a32 = flop / (m32["k_ms"] * 1e-3) / 1e12
-        line["fp32"] = {"value": m32["value"], "unit": "rays/s", "steps": args.fp32_steps, "ms_per_step": m32["ms_per_step"],
-                        "train_rays_per_s": args.n_rand / m32["t_train"], "render_rays_per_s": args.render_rays / m32["t_render"],
-                        "dtype": "f32", "loss_coarse": m32["loss_coarse"], "loss_fine": m32["loss_fine"],
-                        "train_mfma_frac": 3 * FLOP_PER_SAMPLE_FWD * spr * args.n_rand / m32["t_train"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                        "render_mfma_frac": FLOP_PER_SAMPLE_FWD * spr * args.render_rays / m32["t_render"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                        "roofline": {"bound": "mfma", "kernel": "mlp32_fwd_kernel (render fine pass)", "achieved": a32,
-                                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a32 / FP32_MFMA_PEAK_TFLOPS,
-                                     "ms_per_launch": m32["k_ms"], "samples_per_launch": args.render_rays * n_fine}}
-        # the reference-precision measurement where the driver parses it: top level + inside `roofline`
-        line["reference_precision_value"] = m32["value"]
-        line["reference_precision_unit"] = "rays/s (same step, float32 operands: models/NeRF.py:201-243 of the reference runs in MLX float32)"
-        line["roofline"]["reference_precision"] = {
-            "kernel": "mlp32_fwd_kernel (render fine pass, v_mfma_f32_32x32x2_f32)", "dtype": "f32", "value": m32["value"],
-            "unit": "rays/s", "steps": args.fp32_steps, "ms_per_step": m32["ms_per_step"], "achieved": a32,
-            "peak": FP32_MFMA_PEAK_TFLOPS, "achieved_unit": "TFLOP/s", "frac": a32 / FP32_MFMA_PEAK_TFLOPS,
-            "ms_per_launch": m32["k_ms"], "samples_per_launch": args.render_rays * n_fine,
-            "train_rays_per_s": args.n_rand / m32["t_train"], "render_rays_per_s": args.render_rays / m32["t_render"]}
-        # ---- frame: one full 800 x 800 frame through the public render.render() API, both precisions
-        line["frame"] = {"bf16": frame_leg(m["trainer"]), "f32": frame_leg(m32["trainer"])}
+            dl = derived(ml, HP, 1024)
+            line["lego_batch"] = {"n_rand_per_gpu": 1024, **{k: dl[k] for k in ("value", "unit", "steps", "ms_per_step", "train_rays_per_s",
+                                                                                   "render_rays_per_s", "train_mfma_frac", "dtype")}}
+        # ---- the other two precisions of the same step: literal float32 operands on v_mfma_f32_32x32x2_f32 (the REFERENCE's
+        # arithmetic, models/NeRF.py:201-243 runs in MLX float32) and the declared reduced-precision bf16 mode
+        trainers = {HP: m["trainer"]}
+        for prec, key, steps in ((32, "fp32", args.fp32_steps), (16, "bf16", args.steps), (22, "f32tol", args.steps)):
+            if prec == HP:
+                continue
+            mo = measure(prec, steps, 2 if prec == 32 else args.warmup)
+            trainers[prec] = mo.pop("trainer")
+            line[key] = derived(mo, prec, args.n_rand)
+        r32 = line["fp32"] if HP != 32 else hd
+        # the literal-float32 measurement where the driver parses it: top level + inside `roofline`
+        line["reference_precision_value"] = r32["value"]
+        line["reference_precision_unit"] = "rays/s (same step, float32 operands on the fp32 MFMA: models/NeRF.py:201-243 of the reference runs in MLX float32)"
+        line["roofline"]["reference_precision"] = dict(r32["roofline"], dtype="f32", value=r32["value"], value_unit="rays/s", steps=r32["steps"],
+                                                       ms_per_step=r32["ms_per_step"], achieved_unit="TFLOP/s",
+                                                       train_rays_per_s=r32["train_rays_per_s"], render_rays_per_s=r32["render_rays_per_s"])
+        # ---- frame: one full 800 x 800 frame through the public render.render() API, all three precisions
+        line["frame"] = {DTYPE_SHORT[p_]: frame_leg(trainers[p_]) for p_ in (22, 16, 32) if p_ in trainers}
+        trainers.clear()
         # ---- ngp: BASELINE configs[4] (hash grid + 2x64 MLP), its own step and roofline (the table-gradient scatter)
         ngp_line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev)
         line["ngp"] = {k: ngp_line[k] for k in ("value", "unit", "ms_per_step", "steps", "train_rays_per_s_per_gpu",

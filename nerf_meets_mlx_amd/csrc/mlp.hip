@@ -24,10 +24,12 @@
 #include "common.h"
 #include "mlp_ring.h"
 #include "mlp_layout.h"
+#include "mlp_frag.h"
 #include "hash_common.h"
 #include "mlp_params.h"
 #include "mlp32.h"
 #include "mlp22.h"
+#include "mlp_s16.h"
 #include <string.h>
 #include <mutex>
 #include <unordered_map>
@@ -43,69 +45,7 @@ extern int g_hash_combine_max_res;        // encode.hip
 // ------------------------------------------------------------------------------------------
 // weight packing: fp32 master parameters -> bf16 MFMA fragments (+ fp32 bias slots)
 // ------------------------------------------------------------------------------------------
-__device__ float fwd_src(const float* __restrict__ p, int f, int r, int h, int j) {
-  int nt, ks;
-  if (f < L::F_L1) {                                   // pos0: K space 64 (63 + pad)
-    nt = f / 4; ks = f % 4;
-    const int kk = kperm(ks, h, j);
-    return kk < 63 ? p[L::P_W0 + (32 * nt + r) * 63 + kk] : 0.0f;
-  }
-  if (f < L::F_L5) {                                   // pos1..pos4
-    const int l = 1 + (f - L::F_L1) / 128, g = (f - L::F_L1) % 128;
-    nt = g / 16; ks = g % 16;
-    return p[L::pw(l) + (32 * nt + r) * 256 + kperm(ks, h, j)];
-  }
-  if (f < L::F_L6) {                                   // pos5: [PE(64), H4(256)] vs W5[256][319]
-    const int g = f - L::F_L5;
-    nt = g / 20; ks = g % 20;
-    const int kk = kperm(ks, h, j), n = 32 * nt + r;
-    if (kk < 64) return kk < 63 ? p[L::P_W5 + n * 319 + kk] : 0.0f;
-    return p[L::P_W5 + n * 319 + 63 + (kk - 64)];
-  }
-  if (f < L::F_FA) {                                   // pos6, pos7
-    const int l = 6 + (f - L::F_L6) / 128, g = (f - L::F_L6) % 128;
-    nt = g / 16; ks = g % 16;
-    return p[L::pw(l) + (32 * nt + r) * 256 + kperm(ks, h, j)];
-  }
-  if (f < L::F_DIR) {                                  // feature (8 tiles) + alpha (tile 8, row 0)
-    const int g = f - L::F_FA;
-    nt = g / 16; ks = g % 16;
-    const int kk = kperm(ks, h, j);
-    if (nt < 8) return p[L::P_WF + (32 * nt + r) * 256 + kk];
-    return r == 0 ? p[L::P_WA + kk] : 0.0f;
-  }
-  if (f < L::F_RGB) {                                  // dir0: [feature(256), dirPE(27+5 pad)] vs WD[128][283]
-    const int g = f - L::F_DIR;
-    nt = g / 18; ks = g % 18;
-    const int kk = kperm(ks, h, j), n = 32 * nt + r;
-    if (kk < 256) return p[L::P_WD + n * 283 + kk];
-    return (kk - 256) < 27 ? p[L::P_WD + n * 283 + kk] : 0.0f;
-  }
-  ks = f - L::F_RGB;                                   // rgb: rows 0..2 of one tile, K = 128
-  return r < 3 ? p[L::P_WR + r * 128 + kperm(ks, h, j)] : 0.0f;
-}
-
-// transposed stream: A rows = INPUT feature (32 kt + r), k index = OUTPUT feature nn
-__device__ float bwd_src(const float* __restrict__ p, int f, int r, int h, int j) {
-  if (f < L::B_DIR) {                                  // rgb^T: 4 tiles of H_d, one k-step (rows 0..2)
-    const int nn = kperm(0, h, j);
-    return nn < 3 ? p[L::P_WR + nn * 128 + 32 * f + r] : 0.0f;
-  }
-  if (f < L::B_FA) {                                   // dir0^T, feature columns only: 8 tiles x 8 k-steps
-    const int g = f - L::B_DIR, kt = g / 8, ns = g % 8;
-    return p[L::P_WD + kperm(ns, h, j) * 283 + 32 * kt + r];
-  }
-  if (f < L::B_L7) {                                   // [feature; alpha]^T: 8 tiles x 17 k-steps
-    const int g = f - L::B_FA, kt = g / 17, ns = g % 17;
-    const int nn = kperm(ns, h, j);
-    if (ns < 16) return p[L::P_WF + nn * 256 + 32 * kt + r];
-    return nn == 256 ? p[L::P_WA + 32 * kt + r] : 0.0f;
-  }
-  const int g = f - L::B_L7, li = g / 128, q = g % 128, kt = q / 16, ns = q % 16;   // pos7, 6, 5, 4, 3, 2, 1
-  const int l = 7 - li, nn = kperm(ns, h, j), row = 32 * kt + r;
-  if (l == 5) return p[L::P_W5 + nn * 319 + 63 + row];
-  return p[L::pw(l) + nn * 256 + row];
-}
+// fwd_src / bwd_src (fragment element -> master parameter): mlp_frag.h
 
 constexpr int PACK_THREADS = (L::F_TOTAL + L::B_PADDED) * 64 + L::BI_TOTAL;      // one thread per 16-byte lane slot / bias
 __device__ __forceinline__ void pack_part(int tid, const float* __restrict__ p, bf16x8* __restrict__ wf,
@@ -135,12 +75,6 @@ __device__ __forceinline__ void pack_part(int tid, const float* __restrict__ p, 
 // positional encoding straight into B-operand fragments
 // ------------------------------------------------------------------------------------------
 
-struct Chan { int kind, dim, band; };   // kind: 0 identity, 1 sin, 2 cos, 3 zero pad
-__host__ __device__ constexpr Chan chan_of(int c, int limit) {
-  if (c < 3) return Chan{0, c, 0};
-  if (c >= limit) return Chan{3, 0, 0};
-  return Chan{((c - 3) % 6) >= 3 ? 2 : 1, (c - 3) % 3, (c - 3) / 6};
-}
 
 // models/embedding.py:30-71 channel order [x, sin(f0 x), cos(f0 x), ...]; cos(a) = sin(a + 1/4 rev)
 template <int C0, int LIMIT, int NB>
@@ -184,118 +118,7 @@ __device__ __forceinline__ bf16x8 row_frag(const float* __restrict__ row, int ks
 // ------------------------------------------------------------------------------------------
 // one linear layer on register-resident activations
 // ------------------------------------------------------------------------------------------
-// fragment block address: tile T, slot s, lane (r,h) at byte 32 r + 16 h.  Written as (uniform 64-bit tile base) +
-// (constant slot offset) + (32-bit lane offset) so that hipcc keeps the base in SGPRs.
-__device__ __forceinline__ bf16x8* frag_ptr(void* base, int64_t tile, int64_t stride16, int slot, int r, int h) {
-  char* tb = reinterpret_cast<char*>(base) + tile * stride16 * 16;
-  return reinterpret_cast<bf16x8*>(tb + slot * 1024 + (unsigned)(32 * r + 16 * h));
-}
-
-#ifndef NERF_NT_STORES
-#define NERF_NT_STORES 1
-#endif
-constexpr bool g_nt_stores = NERF_NT_STORES != 0;
-
-// one fragment of a fragment block.  Written once, read once by a later kernel: non-temporal, so that the 5 KB/sample
-// store stream does not push the 2.4 MB weight stream (which every workgroup re-reads through the ring) out of L2
-__device__ __forceinline__ void store_frag(void* base, int64_t tile, int64_t stride16, int slot, const bf16x8& v,
-                                           int r, int h) {
-#if NERF_ABLATE == 7          // timing-only build 7: no fragment stores at all (values kept alive)
-  asm volatile("" :: "v"(v));
-  return;
-#endif
-#if NERF_ABLATE == 8          // timing-only build 8: every tile stored over tiles 0-7 (L2-resident: issue cost without HBM)
-  tile = tile & 7;
-#endif
-  if (g_nt_stores) __builtin_nontemporal_store(v, frag_ptr(base, tile, stride16, slot, r, h));
-  else *frag_ptr(base, tile, stride16, slot, r, h) = v;
-}
-template <int COUNT>
-__device__ __forceinline__ void store_frags(void* base, int64_t tile, int64_t stride16, int slot0,
-                                            const bf16x8 (&frags)[COUNT], int r, int h) {
-#pragma unroll
-  for (int k = 0; k < COUNT; ++k) store_frag(base, tile, stride16, slot0 + k, frags[k], r, h);
-}
-// Where a layer's output fragments go besides the next layer: nowhere (inference), or into the fragment block of the
-// sample tile as soon as each pair of fragments is final.  A burst of 16 stores per wave behind the layer (128 KiB per
-// workgroup, all 8 waves at once) backs up the CU's store path and stalls the waves at issue: measured 0.21 ms of a
-// 0.94 ms chain even with the bytes staying in L2 (NERF_ABLATE 8); two stores per n-tile keep the path draining.
-struct NoSink {
-  __device__ __forceinline__ void put(int, int, const bf16x8&) const {}
-};
-template <bool ON>
-struct FragSink {
-  void* base; int64_t tile0, stride16; int slot0, r, h;
-  __device__ __forceinline__ void put(int t, int idx, const bf16x8& v) const {
-    if (ON) store_frag(base, tile0 + t, stride16, slot0 + idx, v, r, h);
-  }
-};
-
-template <class WS>
-__device__ __forceinline__ void acc_init_bias(f32x16& acc, WS& ws, int slot_tile, int h) {
-  // register i <-> row (i&3) + 8 (i>>2) + 4 h : four float4 at rows 8g + 4h
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 b = ws.bias4(slot_tile + 8 * g + 4 * h);
-    acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
-  }
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16x2 pack2(float a, float b) {       // one v_cvt_pk_bf16_f32
-  const f32x2 v = {a, b};
-  return __builtin_convertvector(v, bf16x2);
-}
-__device__ __forceinline__ bf16x2 relu_pack(float a, float b) {
-  s16x2 q = __builtin_bit_cast(s16x2, pack2(a, b));
-  const s16x2 zero = {0, 0};
-  q = __builtin_elementwise_max(q, zero);
-  return __builtin_bit_cast(bf16x2, q);
-}
-// Packed 16-bit integer ops on bf16 bit patterns.  Inline asm on purpose: written as vector arithmetic, hipcc turns
-// them back into one float compare + select per element (and v_perm to re-pack), which is what they replace.
-// ReLU sign bits of a packed, already ReLU'd bf16 pair: 1 per non-zero half.
-__device__ __forceinline__ unsigned nonzero_bits(bf16x2 p) {
-  unsigned r;
-  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, p)));
-  return r;
-}
-// keep a half of the packed pair where bit B of the same half of `w` is set
-template <int B>
-__device__ __forceinline__ bf16x2 keep_where(bf16x2 p, unsigned w) {
-  unsigned sel, r;
-  asm("v_pk_lshrrev_b16 %0, %2, %1 op_sel_hi:[0,1]" : "=v"(sel) : "v"(w), "n"(B));      // both halves shift by the constant's low half
-  sel &= 0x00010001u;
-  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, p)), "v"(sel));
-  return __builtin_bit_cast(bf16x2, r);
-}
-
-// Epilogue of one accumulator tile, in four quarters of 4 registers so that it can be spread between the MFMAs
-// of the NEXT n-tile (the two waves of a SIMD run the same stream in lockstep behind the ring barrier; an epilogue
-// done in one block would leave the matrix pipe idle in both at once).  ReLU is an integer max on the bit pattern:
-// one VALU op, without the canonicalising v_max hipcc puts in front of fmaxf on MFMA results.
-// Sign-bit words (MASKOUT): element e = 2 k + odd of n-tile nt -> bit 16 odd + 8 (nt & 1) + k of word nt >> 1, taken
-// from the packed ReLU'd pairs (non-zero half = active unit) instead of a compare + select per fp32 value.
-template <bool RELU, bool MASKOUT>
-__device__ __forceinline__ void finish_quarter(const f32x16& acc, int q, int nt, bf16x8& lo, bf16x8& hi, u32x4& mask) {
-  unsigned w = 0;
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int i = 4 * q + 2 * p, k = 2 * q + p;
-    const bf16x2 pr = RELU ? relu_pack(acc[i], acc[i + 1]) : pack2(acc[i], acc[i + 1]);
-    if (MASKOUT) w |= nonzero_bits(pr) << k;
-    if (i < 8) { lo[i] = pr[0]; lo[i + 1] = pr[1]; } else { hi[i - 8] = pr[0]; hi[i - 7] = pr[1]; }
-  }
-  if (MASKOUT) mask[nt >> 1] |= w << (8 * (nt & 1));
-}
-
-__host__ __device__ constexpr int quarter_pos(int ks_count, int q) {   // k-step after which quarter q is retired
-  return ks_count >= 8 ? (q * ks_count) / 4 + 1 : (q < ks_count ? q : ks_count - 1);
-}
+// fragment blocks, packed-pair helpers, epilogue schedule, DwJob / DwArgs: mlp_frag.h
 
 // out[t][2 nt + s] = act( W[nt-tile] . in[t] + bias );  fragments fbase + nt*KS + ks of the stream
 template <int ST, int KS, int NT, bool RELU, bool MASKOUT, class WS, class SINK = NoSink>
@@ -1062,32 +885,6 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_bwd_ring_kernel(BwdArgs a) {
 // ------------------------------------------------------------------------------------------
 // dW: split-K GEMMs  dW[n][k] = sum_m dZ[n][m] H[k][m]  over fragment blocks, samples = MFMA K
 // ------------------------------------------------------------------------------------------
-struct DwJob {
-  int dz_slot, nf;        // dZ fragments (16 features each); nf <= 16
-  int act_slot, kf;       // input-activation fragments; kf <= 16
-  int w_off, ldw, col0;   // grads[w_off + n*ldw + col0 + k]
-  int n_valid, k_valid;
-  int b_off;              // bias gradient offset or -1 (only the job with col0 == 0 of a layer owns it)
-};
-constexpr int DW_MAX_JOBS = 16;
-struct DwArgs {
-  DwJob jobs[DW_MAX_JOBS];
-  int splits[DW_MAX_JOBS];  // workgroups per job; block b works on job j, split b - prefix(j)
-  int ntiles;
-  int64_t astride, zstride;
-  const void* acts;
-  const void* dz;
-  float* grads;
-  float* partial;         // [workgroup][DW_SLOT_FLOATS] split-K partial tiles (deterministic two-stage reduction)
-};
-// One slot per dW workgroup: up to 8 x 8 output tiles of 32 x 32 floats (tile (nt, kt) at (8 nt + kt) * 1024, row-major
-// inside the tile) + 8 x 32 bias partial sums.  The workgroups of a job write their partial dW here with plain
-// coalesced stores and mlp_dw_reduce_kernel adds the splits of every element in a FIXED order: no float atomics (they
-// cost 12.6 % of the dW kernel: 157 MB of read-modify-writes at the memory side per launch, whatever the batch size) and
-// the gradient is bit-reproducible from run to run -- with atomics the order of the adds, hence the rounding, was not.
-constexpr int DW_SLOT_FLOATS = 64 * 1024 + 256;
-constexpr int DW_MAX_WGS = 512;
-constexpr int64_t DW_PARTIAL_BYTES = (int64_t)DW_MAX_WGS * DW_SLOT_FLOATS * 4;
 
 constexpr int DW_FRAG_STRIDE = 1152;                 // 1 KiB + 128 B: neighbouring fragments hit disjoint banks
 constexpr int DW_STAGE_BYTES = 32 * DW_FRAG_STRIDE;  // 16 dZ + 16 act fragments per 32-sample tile
@@ -1771,10 +1568,12 @@ static int g_ring_split = 1;     // training ring kernels: 1 = one 8-wave workgr
 // precision of a model = nerf_mlp_arch.precision (ABI 3): 16 (or 0) bf16 MFMA operands with fp32 accumulate, 32 the fp32
 // reference-precision kernels of mlp32.hip.  Nothing process-wide: two models of different precision can be packed,
 // queried and trained side by side on any streams.
-// 22 = split-fp16 inference (mlp22.hip: float32-class accuracy at 1/3 of the fp16 matrix rate) over the fp32 kernels for
-// everything that keeps activations (training forward, backward): such a model carries all three weight images.
+// 22 = the reference-tolerance mode on the 16-bit matrix pipe: split-fp16 inference (mlp22.hip: float32-class accuracy at
+// 1/3 of the fp16 matrix rate) and split-bf16 training (mlp_s16.hip: training forward, dZ chain, dW at 1/3 of the bf16 rate);
+// such a model carries the bf16 image (its fp32 bias slots are shared), the split-fp16 and the split-bf16 streams.
 static inline int arch_prec(const nerf_mlp_arch* a) { return a->precision == 32 ? 32 : a->precision == 22 ? 22 : 16; }
-static inline bool arch_f32(const nerf_mlp_arch* a) { return a->precision == 32 || a->precision == 22; }   // trains on mlp32.hip
+static inline bool arch_f32(const nerf_mlp_arch* a) { return a->precision == 32; }                          // trains on mlp32.hip
+static inline bool arch_s16(const nerf_mlp_arch* a) { return a->precision == 22; }                          // trains on mlp_s16.hip
 // CUs of the current device (256 on an MI355X in SPX mode), asked once: the persistent kernels and the dW split are
 // sized to it instead of to a constant
 // Per-device state: the CU count and the "dynamic LDS attribute set" flags belong to the CURRENT device (a process may
@@ -1810,7 +1609,7 @@ static void ensure_lds(K kernel, int bytes) {
 static int arch_kind(const nerf_mlp_arch* a) {
   if (!a) return -1;
   if (a->precision != 0 && a->precision != 16 && a->precision != 32 && a->precision != 22) return -1;
-  if (arch_f32(a) && !(a->n_layers == 8 && a->width == 256 && a->use_viewdirs == 1)) return -1;   // fp32 / split-fp16 kernels: 8 x 256 view model only
+  if ((arch_f32(a) || arch_s16(a)) && !(a->n_layers == 8 && a->width == 256 && a->use_viewdirs == 1)) return -1;   // fp32 / split-fp16 kernels: 8 x 256 view model only
   if (a->n_layers == 2 && a->width == 64 && a->skip_layer < 0 && a->use_viewdirs == 1 && a->in_pos == 32 && a->in_dir == 16) return 2;
   if (a->n_layers != 8 || a->width != 256 || a->skip_layer != 4) return -1;
   if (a->use_viewdirs == 1 && a->in_pos == 63 && a->in_dir == 27) return 0;
@@ -1868,15 +1667,22 @@ extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
   // an fp32 (precision 32) 8 x 256 view model carries its fp32 streams behind the bf16 image
   // ... and a precision-22 model its split-fp16 stream behind that
-  return k == 0 ? L::PACKED_BYTES + (arch_f32(arch) ? f32::PACKED_BYTES : 0) + (arch_prec(arch) == 22 ? f22::PACKED_BYTES : 0) : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
+  return k == 0 ? L::PACKED_BYTES + (arch_f32(arch) ? f32::PACKED_BYTES : 0) + (arch_s16(arch) ? f22::PACKED_BYTES + s16::PACKED_BYTES : 0) : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
 }
 static inline const void* packed32_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES; }
-static inline const void* packed22_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES + f32::PACKED_BYTES; }
+static inline const void* packed22_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES; }
+static inline const void* packed_s16_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES + f22::PACKED_BYTES; }
+static inline const float* bias_slots_of(const void* packed) {
+  return reinterpret_cast<const float*>(static_cast<const char*>(packed) + (size_t)(L::F_TOTAL + L::B_PADDED) * 1024);
+}
+static inline int64_t s16_astride16() { return (int64_t)s16::A_SLOTS * 64 + g_tile_pad16; }
+static inline int64_t s16_zstride16() { return (int64_t)s16::Z_SLOTS * 64 + g_tile_pad16; }
 static inline int64_t padded_tiles(int64_t M) { return (((M + 31) / 32) + 7) / 8 * 8; }
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
   const int64_t b16 = padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16() : small_astride16()) * 16;
+  if (k == 0 && arch_s16(arch)) return padded_tiles(M) * s16_astride16() * 16;
   return (k == 0 && arch_f32(arch)) ? f32::acts_bytes(M) : b16;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
@@ -1884,6 +1690,7 @@ extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
   if (k < 0 || M < 0) return -1;
   const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16
                       + DW_PARTIAL_BYTES;                 // + the split-K partial tiles of the weight-gradient kernel
+  if (k == 0 && arch_s16(arch)) return padded_tiles(M) * s16_zstride16() * 16 + DW_PARTIAL_BYTES;
   return (k == 0 && arch_f32(arch)) ? f32::dz_bytes(M) : b16;
 }
 
@@ -1919,7 +1726,8 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
   int rc = check_launch("nerf_mlp_pack");
   if (rc) return rc;
   if (arch_f32(arch)) rc = f32::pack(params, base + L::PACKED_BYTES, as_stream(stream));
-  if (!rc && arch_prec(arch) == 22) rc = f22::pack(params, base + L::PACKED_BYTES + f32::PACKED_BYTES, as_stream(stream));
+  if (!rc && arch_s16(arch)) rc = f22::pack(params, base + L::PACKED_BYTES, as_stream(stream));
+  if (!rc && arch_s16(arch)) rc = s16::pack(params, base + L::PACKED_BYTES + f22::PACKED_BYTES, as_stream(stream));
   return rc;
 }
 
@@ -2034,8 +1842,11 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     return check_launch("mlp forward (image model)");
   }
-  if (arch_prec(arch) == 22 && !acts)          // inference: split fp16 on the 16-bit matrix pipe
+  if (arch_s16(arch) && !acts)                 // inference: split fp16 on the 16-bit matrix pipe
     return f22::forward(packed22_of(packed), x, nullptr, nullptr, M, 1, 0, out, ring_wgs(), as_stream(stream));
+  if (arch_s16(arch))                          // training forward: split bf16, hi + lo fragment blocks kept
+    return s16::forward(packed_s16_of(packed), bias_slots_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, s16_astride16(),
+                        ring_wgs(), as_stream(stream));
   if (arch_f32(arch)) {
     return f32::forward(packed32_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, as_stream(stream));
   }
@@ -2055,8 +1866,11 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   NERF_REQUIRE(packed && rays && z && raw, NERF_E_NULL, "nerf_query_fused: NULL pointer");
   NERF_REQUIRE(freq_mode == 0 || freq_mode == 1, NERF_E_UNSUPPORTED, "nerf_query_fused: freq_mode must be 0 or 1");
   NERF_REQUIRE(B * (int64_t)n < (1ll << 31), NERF_E_SHAPE, "nerf_query_fused: B*n must be < 2^31 samples per call");
-  if (arch_prec(arch) == 22 && !acts)
+  if (arch_s16(arch) && !acts)
     return f22::forward(packed22_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, ring_wgs(), as_stream(stream));
+  if (arch_s16(arch))
+    return s16::forward(packed_s16_of(packed), bias_slots_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts,
+                        s16_astride16(), ring_wgs(), as_stream(stream));
   if (arch_f32(arch)) {
     return f32::forward(packed32_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts, as_stream(stream));
   }
@@ -2065,7 +1879,7 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
 
 // split the (dZ, H) jobs over workgroups and launch the dW kernel; grads[0..nparams) is overwritten
 static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
-                     int64_t zstride, float* grads, hipStream_t s) {
+                     int64_t zstride, float* grads, hipStream_t s, bool split_bf16 = false) {
   // A job's cost per sample tile = its bytes (nf + kf KiB) + a fixed part (barrier, waits, the 4 DMA issues per wave,
   // transposed reads, MFMAs) worth about 128 KiB of streaming: single-job timings fit t = a (nf + kf + c0) with c0 = 24
   // at a full grid, but under load the sweep over c0 keeps improving up to ~128 and is flat beyond (tools/sweep_dw.py).  Split the sample range of every job in proportion.
@@ -2116,11 +1930,16 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   d.acts = acts; d.dz = dz; d.grads = grads;
   // the partial-tile slots live behind the dZ fragment blocks in the caller's dz workspace (nerf_mlp_dz_bytes counts them)
   d.partial = reinterpret_cast<float*>(static_cast<char*>(dz) + padded_tiles(ntiles * 32) * zstride * 16);
-  static DevOnce lds_attr_set;
-  if (lds_attr_set.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-  hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
-  int rc = check_launch("mlp dW");
+  int rc;
+  if (split_bf16) {            // hi + lo fragment blocks, three MFMAs per product (mlp_s16.hip); same jobs, slots and reduce
+    rc = s16::launch_dw_kernel(d, nw, s);
+  } else {
+    static DevOnce lds_attr_set;
+    if (lds_attr_set.first())
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
+    rc = check_launch("mlp dW");
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(257, nj), dim3(256), 0, s, d);        // 256 x 256 weights + 256 biases: one element per thread
   return check_launch("mlp dW reduce");
@@ -2186,12 +2005,19 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   if (arch_f32(arch)) {
     return f32::backward(packed32_of(packed), acts, d_raw, M, dz, grads, s);
   }
+  const bool split = arch_s16(arch);
+  const int64_t astr = split ? s16_astride16() : astride16(), zstr = split ? s16_zstride16() : zstride16();
+  if (split && g_bwd_stage != 2) {
+    int rcs = s16::backward_chain(packed_s16_of(packed), acts, d_raw, M, dz, astr, zstr, ring_wgs(), s);
+    if (rcs) return rcs;
+  }
   // ---- 1. dZ chain
   BwdArgs b;
   b.wb = reinterpret_cast<const bf16x8*>(static_cast<const char*>(packed) + (size_t)L::F_TOTAL * 1024);
   b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz; b.astride = astride16(); b.zstride = zstride16();
   const int variant = g_mlp_variant == 0 ? 3 : g_mlp_variant;
-  if (variant >= 3) {
+  if (split) {
+  } else if (variant >= 3) {
     if (g_bwd_stage != 2 && g_ring_split == 2) {
       const int64_t nsuper = (ntiles + SPLIT_NW - 1) / SPLIT_NW;
       const int64_t wgs = 2 * (int64_t)ring_wgs();
@@ -2234,7 +2060,7 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   job(L::Z_D, 8, L::A_FEAT, 16, L::P_WD, 283, 0, 128, 256, L::P_BD);                               // dir0 | feature
   job(L::Z_D, 8, L::A_DPE, 2, L::P_WD, 283, 256, 128, 27, -1);                                     // dir0 | dirPE
   job(L::Z_RGB, 1, L::A_HD, 8, L::P_WR, 128, 0, 3, 128, L::P_BR);                                  // rgb
-  return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astride16(), zstride16(), grads, s);
+  return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astr, zstr, grads, s, split);
 }
 
 extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
@@ -2278,7 +2104,7 @@ extern "C" int nerf_mlp_backward_inputs(const nerf_mlp_arch* arch, const void* p
 // ---- test hook: one layer of the training stores (fragment blocks) as row-major fp32 ----------------------------
 namespace nerf {
 __global__ void __launch_bounds__(256) decode_frags_kernel(const void* base, int64_t stride16, int slot0, int nfrag,
-                                                           int64_t M, float* __restrict__ out) {
+                                                           int64_t M, float* __restrict__ out, int lo_off) {
   const int64_t total = M * nfrag * 2;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int h = (int)(t & 1), ks = (int)((t >> 1) % nfrag);
@@ -2286,6 +2112,11 @@ __global__ void __launch_bounds__(256) decode_frags_kernel(const void* base, int
     const bf16x8 v = *frag_ptr(const_cast<void*>(base), m >> 5, stride16, slot0 + ks, (int)(m & 31), h);
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[m * (16 * nfrag) + kperm(ks, h, j)] = (float)v[j];
+    if (lo_off > 0) {           // split-bf16 stores: value = hi block + lo block
+      const bf16x8 w = *frag_ptr(const_cast<void*>(base), m >> 5, stride16, slot0 + lo_off + ks, (int)(m & 31), h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[m * (16 * nfrag) + kperm(ks, h, j)] += (float)w[j];
+    }
   }
 }
 // (slot, fragments) of `layer` in the activation (kind 0) or dZ (kind 1) store of the 8 x 256 view model
@@ -2331,7 +2162,8 @@ extern "C" int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store,
   NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");
   if (M <= 0) return NERF_OK;
   hipLaunchKernelGGL(decode_frags_kernel, dim3(grid_for(M * nfrag * 2, 256)), dim3(256), 0, as_stream(stream), store,
-                     kind == 0 ? astride16() : zstride16(), slot, nfrag, M, out);
+                     arch_s16(arch) ? (kind == 0 ? s16_astride16() : s16_zstride16()) : (kind == 0 ? astride16() : zstride16()), slot, nfrag,
+                     M, out, arch_s16(arch) ? (kind == 0 ? s16::A_LO : s16::Z_LO) : 0);
   return check_launch("nerf_mlp_debug_read");
 }
 

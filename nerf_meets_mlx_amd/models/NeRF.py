@@ -36,9 +36,10 @@ class NeRF:
     """Same constructor arguments as `mlx_nerf/models/NeRF.py:160-199`.  Initialisation is
     mlx.nn.Linear's: weight and bias ~ U(-1/sqrt(in), 1/sqrt(in)) (seeded numpy stream).
     precision (ours): 16 = bf16 MFMA operands with fp32 accumulate (the benchmarked mode), 32 = the reference's own
-    float32 arithmetic on the fp32 MFMA (8 x 256 view model only), 22 = the same for everything that trains, and the
-    split-fp16 kernel (csrc/mlp22.hip: float32 operands as hi + lo fp16 pairs, three fp16 MFMAs per product, float32-class
-    accuracy at ~4 x the fp32 MFMA's speed) for inference.  It is part of the model (`nerf_mlp_arch.precision`):
+    float32 arithmetic on the fp32 MFMA (8 x 256 view model only), 22 = the reference's float32 TOLERANCE on the 16-bit
+    matrix pipe: split-fp16 inference (csrc/mlp22.hip: float32 operands as hi + lo fp16 pairs, three fp16 MFMAs per product,
+    float32-class accuracy at ~3.3 x the fp32 MFMA's speed) and split-bf16 training (csrc/mlp_s16.hip: hi + lo bf16 pairs,
+    forward 1e-5 / gradients 3e-5 of the fp32 oracle at ~2.5 x).  It is part of the model (`nerf_mlp_arch.precision`):
     weight image, workspaces and every launch of this object use it; models of both kinds can be used side by side."""
 
     def __init__(self, n_layers=8, width_layers=256, channel_input=3, channel_input_views=3, channel_output=4,
@@ -56,8 +57,8 @@ class NeRF:
                               self.list_skip_connection_layers[0] if len(self.list_skip_connection_layers) == 1 else -1,
                               int(bool(is_use_view_directions)), channel_output, int(precision))
         if precision not in (16, 22, 32):
-            raise ValueError("NeRF: precision must be 16 (bf16 MFMA operands), 32 (fp32 MFMA) or 22 (fp32 MFMA for training, "
-                             "split-fp16 MFMA at float32 tolerance for inference)")
+            raise ValueError("NeRF: precision must be 16 (bf16 MFMA operands), 32 (fp32 MFMA) or 22 (float32 tolerance on the "
+                             "16-bit matrix pipe: split-bf16 training, split-fp16 inference)")
         self.precision = int(precision)
         self.out_dim = 4 if is_use_view_directions else channel_output
         rng = np.random.default_rng(seed)

@@ -154,3 +154,116 @@ def test_ngp_deterministic_scatter_surfaces_nonfinite_and_out_of_range_gradients
     untouched = (t == before)
     assert bool(untouched.any())                          # entries the batch never touched keep their values
     assert int(tr.field.enc.grad.abs().max()) == 0        # consumed and cleared all the same
+
+
+# ------------------------------------------------------------------------------------------------ a11 adjoint: split-bf16 training
+@pytest.mark.parametrize("B,n", [(64, 96), (37, 45), (300, 64)])
+def test_split_bf16_training_kernels_vs_fp32_oracle(B, n):
+    """NeRF(precision=22) trains on csrc/mlp_s16.hip (every float32 GEMM operand as a bf16 (hi, lo) pair, three bf16 MFMAs
+    per product).  Against the fp32 oracle (torch autograd):
+    (1) training forward <= 1e-4 of the output scale (the bar of the fp32 MFMA kernels), every stored activation <= 1e-4 of
+        its layer's scale, the encodings to 1e-5 of theirs;
+    (2) the ReLU decisions agree except for units whose pre-activation is ~0: < 1e-4 of the units per layer;
+    (3) with the oracle's backward run on the KERNEL's ReLU decisions (masks=...), dW / db agree for EVERY tensor at rel-L2
+        <= 1e-4 and rel-max <= 1e-3, every dZ at rel-L2 <= 1e-4 -- ten times inside the bars of the fp32 MFMA kernels
+        (tests/test_gpu_round2.py::test_fp32_mode_backward_and_training_step: 1e-3 / 1e-2).  Free-running (oracle on its own
+        decisions) the comparison measures the handful of flipped units, not arithmetic (a random-signed upstream gradient
+        makes each flip count in full: tests/test_oracle_golden.py::test_oracle_gradient_noise_floor): <= 2e-2 there.
+    (37, 45): a ragged last sample tile (1665 samples = 52 tiles + 1) and a workgroup with idle waves."""
+    from tests.test_gpu_round2 import LAYER_NAMES, _model_pair, _rays, _rel_l2, _relmax
+    from nerf_meets_mlx_amd.models.NeRF import debug_layer
+    m, arch, flat = _model_pair(3, 1.5, precision=22)
+    torch.manual_seed(5 + B)
+    rays = _rays(B, 77)
+    z = torch.sort(torch.rand(B, n) * 4 + 2, -1).values
+    g = torch.randn(B, n, 4)
+    raw = m.query(rays.to(DEV), z.to(DEV), train=True)
+    grads = m.backward(g.to(DEV)).cpu()
+    o, d, _, _, vd = O.decompose_ray_batch(rays)
+    pos = o[:, None, :] + z[:, :, None] * d[:, None, :]
+    # (1) + (2): free-running oracle
+    fl0 = flat.clone().requires_grad_(True)
+    taps = {}
+    out = O.run_model(arch, O.unflatten_params(arch, fl0), pos, vd, taps=taps)
+    (out * g).sum().backward()
+    e_fwd = _relmax(raw.cpu(), out.detach())
+    assert e_fwd < 1e-4, e_fwd
+    # the inference kernel (split fp16) and the training kernel (split bf16) of the same model agree to the same bar
+    assert _relmax(m.query(rays.to(DEV), z.to(DEV)).cpu(), raw.cpu()) < 1e-4
+    masks, flips_max = {}, 0.0
+    for li, name in enumerate(LAYER_NAMES):
+        act = debug_layer(m, "acts", li).cpu()
+        want = taps[name].detach()
+        assert act.shape == want.shape and _relmax(act, want) < 1e-4, (name, _relmax(act, want))
+        if name != "feature":
+            masks[name] = act > 0
+            flips = float((masks[name] != (want > 0)).float().mean())
+            flips_max = max(flips_max, flips)
+            assert flips < 1e-4, (name, flips)
+    pe = debug_layer(m, "acts", 10).cpu()
+    xe = O.embed(pos, vd)
+    # 16 significand bits: 2^-17 of the value (the identity channels reach |x| ~ 6)
+    assert _relmax(pe[:, :63], xe[:, :63]) < 1e-5 and float(pe[:, 63].abs().max()) == 0.0
+    dpe = debug_layer(m, "acts", 11).cpu()
+    assert _relmax(dpe[:, :27], xe[:, 63:]) < 1e-5 and float(dpe[:, 27:].abs().max()) == 0.0
+    free = _rel_l2(grads, fl0.grad)
+    assert free < 2e-2, free
+    # (3): oracle backward on the kernel's ReLU decisions
+    fl = flat.clone().requires_grad_(True)
+    taps2 = {}
+    out2 = O.run_model(arch, O.unflatten_params(arch, fl), pos, vd, masks=masks, taps=taps2)
+    for t in taps2.values():
+        t.retain_grad()
+    (out2 * g).sum().backward()
+    off, worst = 0, (0.0, None)
+    for name, o_, i_ in arch.layer_shapes():
+        for part, cnt in (("W", o_ * i_), ("b", o_)):
+            a, b = grads[off:off + cnt], fl.grad[off:off + cnt]
+            l2, mx = _rel_l2(a, b), _relmax(a, b)
+            worst = max(worst, (l2, (name, part)))
+            assert l2 < 1e-4 and mx < 1e-3, (name, part, l2, mx)
+            off += cnt
+    assert off == 595844
+    for li, name in enumerate(LAYER_NAMES):
+        dz = debug_layer(m, "dz", li).cpu()
+        ref = taps2[name].grad if name == "feature" else taps2[name].grad * masks[name].float()
+        assert _rel_l2(dz, ref) < 1e-4, (name, _rel_l2(dz, ref))
+    print(f"[s16 B={B} n={n}] forward {e_fwd:.2e} of scale; ReLU flips <= {flips_max:.1e}; mask-aligned worst dW/db rel-L2 "
+          f"{worst[0]:.2e} at {worst[1]}, total {_rel_l2(grads, fl.grad):.2e}; free-running total {free:.2e}")
+
+
+def test_split_bf16_rows_entry_trainer_and_reproducibility():
+    """precision 22: NeRF.forward(x, train=True) on embedded rows takes the same kernels; three Trainer iterations follow the
+    fp32 OracleTrainer (losses within 1e-3, weights rel-L2 <= 1e-3); the gradient of one batch computed twice is bit-identical
+    (plain-store split-K partial tiles + fixed-order reduce, as for the other precisions)."""
+    from tests.test_gpu_round2 import _model_pair, _rays, _rel_l2, _relmax
+    from nerf_meets_mlx_amd.dataset import synthetic
+    from nerf_meets_mlx_amd.engine.trainer import Trainer
+    m, arch, flat = _model_pair(3, 1.5, precision=22)
+    rows = torch.randn(100, 90, generator=torch.Generator().manual_seed(3))
+    want = O.nerf_forward(arch, O.unflatten_params(arch, flat), rows)
+    assert _relmax(m.forward(rows.to(DEV), train=True).cpu(), want) < 1e-4
+    assert _relmax(m.forward(rows.to(DEV)).cpu(), want) < 1e-4
+    rays, z = _rays(200, 5).to(DEV), torch.sort(torch.rand(200, 64, generator=torch.Generator().manual_seed(1)) * 4 + 2, -1).values.to(DEV)
+    g = torch.randn(200, 64, 4, generator=torch.Generator().manual_seed(2)).to(DEV)
+    m.query(rays, z, train=True)
+    g1 = m.backward(g).clone()
+    m.grads.fill_(float("nan"))
+    m.query(rays, z, train=True)
+    g2 = m.backward(g)
+    assert torch.equal(g1, g2) and torch.isfinite(g2).all()
+    H = W = 24
+    imgs, poses, _, _, K = synthetic.make_dataset(H, W, 3, seed=0, device=DEV)
+    tr = Trainer(imgs, poses, K, N_rand=128, n_depth_samples=64, N_importance=128, seed=4, device=DEV, precision=22)
+    ot = O.OracleTrainer(arch, 64, 128, seed=4)
+    gen = torch.Generator().manual_seed(3)
+    for it in range(3):
+        r, t = tr.sample_batch()
+        u = torch.rand(128, 128, generator=gen)
+        lh = tr.train_step(r, t, u.to(DEV))
+        lo = ot.step(r[:, 0:3].cpu(), r[:, 3:6].cpu(), t.cpu(), u)
+        assert abs(float(lh["loss_coarse"]) - lo["loss_coarse"]) <= 1e-3 * abs(lo["loss_coarse"]), (it, lh, lo)
+        assert abs(float(lh["loss_fine"]) - lo["loss_fine"]) <= 1e-3 * abs(lo["loss_fine"]), (it, lh, lo)
+    # Adam without bias correction steps ~ lr * g / (|g| + eps): where |g| ~ eps a 1e-5 relative gradient difference is a
+    # visible step difference; 3 steps of lr 5e-4 on weights of scale 0.06 bound the drift (measured 2.5e-4)
+    assert _rel_l2(tr.coarse.params.cpu(), ot.pc.detach()) < 1e-3

@@ -2,7 +2,7 @@
 # Extra PMC passes (own runs, counters only): matrix-pipe busy cycles + GPU active cycles, LDS conflicts.
 set -e
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
@@ -16,7 +16,7 @@ def load(d):
     f = sorted(glob.glob("$O/" + d + "/**/*_counter_collection.csv", recursive=True))[-1]
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if "nerf::mlp" in r["Kernel_Name"]:
+        if "nerf::mlp" in r["Kernel_Name"] or "nerf::s16" in r["Kernel_Name"] or "nerf::f22" in r["Kernel_Name"]:
             k = (r["Kernel_Name"].replace("void ", "").split("(")[0], int(r["Grid_Size"]))
             per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             per[k]["us:" + r["Counter_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

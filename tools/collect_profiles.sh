@@ -2,12 +2,12 @@
 # Runs on the GPU box (gpurun): bench line, rocprofv3 kernel stats, the two PMC passes.  Raw output under gpurun_out/.
 set -e
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python bench.py > $O/bench_n1.json.log 2> $O/bench_n1.err      # the default line: burst + sustained + fp32 + ngp legs + cpu_baseline
-python bench.py --steps 10 --warmup 3 --hw 400 --n-importance 0 --no-cpu-baseline --no-extra-legs > $O/bench_cfg1_400_coarse_only.json.log 2>> $O/bench_n1.err
+python bench.py --steps 10 --warmup 3 --hw 400 --n-importance 0 --precision 16 --no-cpu-baseline --no-extra-legs > $O/bench_cfg1_400_coarse_only.json.log 2>> $O/bench_n1.err
 python bench.py --steps 10 --warmup 3 --n-rand 1024 --no-cpu-baseline --no-extra-legs > $O/bench_nrand1024.json.log 2>> $O/bench_n1.err
 python bench.py --steps 10 --warmup 3 --config ngp > $O/bench_configs4_ngp.json.log 2>> $O/bench_n1.err
 python tools/bench_kernels.py > $O/hbm_kernels.csv 2>> $O/bench_n1.err

@@ -33,7 +33,15 @@ DYNAMIC_LDS = {
     "mlp_small_fwd_kernel": 32 * 1024 + 288 * 4,              # LN::LDS_BYTES: resident fragment stream + biases
     "mlp_small_bwd_kernel": 32 * 1024 + 288 * 4,
     "mlp32_fwd_kernel": 4 * 256 * 32 * 4, "mlp32_bwd_kernel": 4 * 256 * 32 * 4,     # one 32 KiB slab per wave
+    "mlp22_fwd_kernel": 4 * 32 * 1024 + 2560 * 4,             # split-fp16 render forward: the same ring
+    "s16_fwd_kernel": 4 * 32 * 1024 + 2560 * 4, "s16_bwd_kernel": 4 * 32 * 1024 + 2560 * 4,   # split-bf16 training: the same ring
+    "s16_dw_kernel": 4 * 32 * 1024 + 1024,                    # 4 stages x 32 pair blocks of 1 KiB + sink
 }
+
+
+def is_render_forward(name):
+    """the inference forward of the render path: bf16 (16x16x32 / 32x32x16 ring kernels) or split fp16 (precision 22)"""
+    return "mlp_fwd_ring16_kernel" in name or "mlp22_fwd_kernel" in name or name.startswith("nerf::mlp_fwd_ring_kernel<1, false>")
 
 
 def dynamic_lds(name):
@@ -78,7 +86,7 @@ def main():
             for k, v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
                 w.writerow(list(k) + [dynamic_lds(k[0]), len(v), f"{statistics.mean(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}"])
         # the render-path forward kernel, split by launch duration class (coarse 64 / fine 192 samples per ray)
-        fwd = [(k, v) for k, v in groups.items() if "mlp_fwd_ring16_kernel" in k[0] or k[0].startswith("nerf::mlp_fwd_ring_kernel<1, false>")]
+        fwd = [(k, v) for k, v in groups.items() if is_render_forward(k[0])]
         with open(os.path.join(a.out, f"{R}_dominant_kernel_launches.csv"), "w", newline="") as fp:
             w = csv.writer(fp)
             w.writerow(["kernel", "class", "samples_per_launch", "launches", "avg_us", "min_us", "max_us", "algorithmic_TFLOPs"])
@@ -94,7 +102,7 @@ def main():
         per = defaultdict(lambda: defaultdict(list))
         for ctr, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
             for r in csv.DictReader(open(find(d, "_counter_collection.csv"))):
-                if "nerf::mlp" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                if ("nerf::mlp" in r["Kernel_Name"] or "nerf::s16" in r["Kernel_Name"] or "nerf::f22" in r["Kernel_Name"]) and r["Counter_Name"] == ctr:
                     per[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][ctr].append(
                         (float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
         with open(os.path.join(a.out, f"{R}_pmc_mlp_kernels.csv"), "w", newline="") as fp:
@@ -106,7 +114,7 @@ def main():
                 wr = max((x[0] for x in c["WRITE_SIZE"]), default=0.0)
                 us = statistics.mean([x[1] for x in c["FETCH_SIZE"] + c["WRITE_SIZE"]])
                 w.writerow([k, g, len(c["FETCH_SIZE"]), f"{f:.0f}", f"{wr:.0f}", f"{us:.1f}"])
-                if ("mlp_fwd_ring16_kernel" in k or k.startswith("nerf::mlp_fwd_ring_kernel<1, false>")) and (best is None or wr > best[2]):
+                if is_render_forward(k) and (best is None or wr > best[2]):
                     best = (k, f, wr)
         if best:
             with open(os.path.join(a.out, f"{R}_pmc_traffic.json"), "w") as fp:
