@@ -197,7 +197,15 @@ class Trainer:
                 "params": {k: m.params.detach().cpu().clone() for k, m in self._checkpoint_buffers().items()},
                 "adam": self.opt.state_dict()}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, allow_legacy_rng: bool = False):
+        """allow_legacy_rng: accept a round-1/2 state (saved RNG states `rng_numpy*` / `rng_torch`, or no `seed`): its
+        continuation here is NOT the one the file's writer would have produced (the streams are now functions of
+        (seed, rank, iteration)); refused unless the caller says so."""
+        legacy = [k for k in sd if str(k).startswith("rng_")]
+        if (legacy or "seed" not in sd) and not allow_legacy_rng:
+            raise ValueError("checkpoint predates the stateless random streams (" + (", ".join(legacy) or "no `seed` entry") +
+                             "): resuming it is not a bit-identical continuation of the run that wrote it; pass "
+                             "allow_legacy_rng=True to continue on this trainer's (seed, rank, iteration) streams anyway")
         self.it = int(sd["it"])
         bufs = self._checkpoint_buffers()
         params = sd.get("params", {k: sd[k] for k in bufs if k in sd})       # round-1 layout: parameters at top level
@@ -213,6 +221,7 @@ class Trainer:
         if "seed" in sd:
             self.seed = int(sd["seed"])      # the streams are functions of (seed, rank, it): adopt the saved run's seed so that
                                              # this trainer CONTINUES it, whatever seed its own (now overwritten) init used
+            self.gen.manual_seed(parallel.rank_seed(self.seed, self.rank, 2))      # evaluation-time uniforms follow the adopted seed
 
     @staticmethod
     def _npz_path(path: str) -> str:
@@ -237,7 +246,7 @@ class Trainer:
         os.replace(tmp, path)                                   # never leave a half-written checkpoint under the final name
         return path
 
-    def load(self, path: str):
+    def load(self, path: str, allow_legacy_rng: bool = False):
         import json
         path = path if os.path.exists(path) else self._npz_path(path)
         z = np.load(path)
@@ -253,5 +262,8 @@ class Trainer:
             sd["adam"]["learning_rate"] = float(z["adam_lr"])
         if "seed" in z.files:
             sd["seed"] = int(z["seed"])
-        self.load_state_dict(sd)
+        for k in z.files:
+            if k.startswith("rng_"):
+                sd[k] = True                 # round-1/2 file: saved RNG states this trainer no longer uses
+        self.load_state_dict(sd, allow_legacy_rng=allow_legacy_rng)
         return sd["it"]

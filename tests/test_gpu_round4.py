@@ -267,3 +267,28 @@ def test_split_bf16_rows_entry_trainer_and_reproducibility():
     # Adam without bias correction steps ~ lr * g / (|g| + eps): where |g| ~ eps a 1e-5 relative gradient difference is a
     # visible step difference; 3 steps of lr 5e-4 on weights of scale 0.06 bound the drift (measured 2.5e-4)
     assert _rel_l2(tr.coarse.params.cpu(), ot.pc.detach()) < 1e-3
+
+
+def test_checkpoint_from_before_the_stateless_streams_is_refused_unless_opted_in(tmp_path):
+    """A round-1/2 checkpoint (saved RNG states, no `seed`) cannot be continued bit-identically any more: load() says so
+    instead of silently switching streams (advisor, round 3); adopting a saved seed also reseeds the evaluation generator."""
+    from nerf_meets_mlx_amd.dataset import synthetic
+    from nerf_meets_mlx_amd.engine.trainer import Trainer
+    imgs, poses, _, _, K = synthetic.make_dataset(16, 16, 2, seed=0, device=DEV)
+    a = Trainer(imgs, poses, K, N_rand=32, seed=11, device=DEV)
+    a.train_step()
+    sd = a.state_dict()
+    legacy = {k: v for k, v in sd.items() if k != "seed"}
+    legacy["rng_torch"] = torch.zeros(8, dtype=torch.uint8)
+    b = Trainer(imgs, poses, K, N_rand=32, seed=99, device=DEV)
+    with pytest.raises(ValueError, match="predates the stateless random streams"):
+        b.load_state_dict(legacy)
+    b.load_state_dict(legacy, allow_legacy_rng=True)
+    assert b.it == 1 and b.seed == 99 and torch.equal(b.coarse.params, a.coarse.params)
+    c = Trainer(imgs, poses, K, N_rand=32, seed=99, device=DEV)
+    c.load_state_dict(sd)
+    assert c.seed == 11
+    rays = a.sample_batch()[0]
+    assert torch.equal(torch.rand(4, device=DEV, generator=c.gen), torch.rand(4, device=DEV, generator=Trainer(imgs, poses, K, N_rand=32, seed=11, device=DEV).gen))
+    path = a.save(str(tmp_path / "ck"))
+    assert c.load(path) == 1
