@@ -305,6 +305,15 @@ int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store, int kind, 
 int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z, int64_t B,
                          int n, const float* tables, int L, int log2_T, int F, const int* resolutions_host,
                          int sh_degree, float pos_scale, float pos_offset, float* raw, void* acts, void* stream);
+/* Round 4: the same query gathering from an fp16 SHADOW image of the tables (tables_half: [L,T] packed pairs of fp16, 4
+ * bytes per entry instead of the 8 of the float32 master pair; NULL = gather `tables`) -- SURVEY 8(d) budgets 512 B of
+ * gathers per sample, the float32 pairs are 1024.  Interpolation stays float32.  The shadow is written by
+ * nerf_adam_step_shadow in the pass that updates the float32 master tables (encoding/multi_hash.py:79-136 keeps one
+ * float32 table; the shadow is this library's, like the packed weight image of the MLPs).                         */
+int nerf_ngp_query_fused_h(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z, int64_t B,
+                           int n, const float* tables, const void* tables_half, int L, int log2_T, int F,
+                           const int* resolutions_host, int sh_degree, float pos_scale, float pos_offset, float* raw,
+                           void* acts, void* stream);
 
 /* ---------------------------------------------------------------- fused renderer (a14 / a18)
  * replaces: rendering/render.py:164-241 render_rays_eval (coarse pass, importance sampling, sort, second pass)
@@ -361,6 +370,11 @@ int nerf_adam_step(float* params, const float* grads, float* m, float* v, int64_
 int nerf_adam_step_ex(float* params, void* grads, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                       float eps, int bias_correction, int step, float grad_scale, int grads_fixed_point, int zero_grads,
                       void* stream);
+/* nerf_adam_step_ex that also writes every updated parameter as fp16 to params_half [count] (NULL: exactly
+ * nerf_adam_step_ex): the shadow image nerf_ngp_query_fused_h gathers from, kept current at no extra pass.       */
+int nerf_adam_step_shadow(float* params, void* grads, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                          float eps, int bias_correction, int step, float grad_scale, int grads_fixed_point, int zero_grads,
+                          void* params_half, void* stream);
 
 #ifdef __cplusplus
 }

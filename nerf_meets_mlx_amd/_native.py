@@ -31,6 +31,7 @@ SIGNATURES = {
     "nerf_hashgrid_backward": (_I, [_P, _I64, _P, _I, _I, _I, C.POINTER(C.c_int), _P, _P]),
     "nerf_ngp_encode": (_I, [_P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), _I, C.c_float, C.c_float, _P, _P, _P]),
     "nerf_ngp_query_fused": (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), _I, C.c_float, C.c_float, _P, _P, _P]),
+    "nerf_ngp_query_fused_h": (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _I, _I, _I, C.POINTER(C.c_int), _I, C.c_float, C.c_float, _P, _P, _P]),
     "nerf_hashgrid_backward_rays": (_I, [_P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), C.c_float, C.c_float, _P, _P]),
     "nerf_hashgrid_backward_ex": (_I, [_P, _I64, _P, _I, _I, _I, C.POINTER(C.c_int), _I, _I, _I, _P, _P]),
     "nerf_hashgrid_backward_rays_ex": (_I, [_P, _P, _I64, _I, _P, _I, _I, _I, C.POINTER(C.c_int), C.c_float, C.c_float, _I, _I, _I, _P, _P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "nerf_get_option": (_I, [C.c_char_p]),
     "nerf_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _I, _F, _P]),
     "nerf_adam_step_ex": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _I, _F, _I, _I, _P]),
+    "nerf_adam_step_shadow": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _I, _F, _I, _I, _P, _P]),
 }
 
 

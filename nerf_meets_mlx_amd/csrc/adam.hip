@@ -23,10 +23,12 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 // The same update with (a) the gradient taken from float32 values OR from the int64 fixed-point accumulators of the
 // deterministic hash-grid scatter (hash_common.h: 2^-52 units), and (b) the gradient buffer zeroed in the same pass
 // (read g, write 0): the next step's scatter needs no memset launch.
-template <bool FIXED, bool ZERO>
+// (c) SHADOW: the updated parameter is also written as fp16 into a second buffer -- the 4-byte-per-entry image of the hash
+// tables that the forward gathers read (half the bytes of the float32 master pairs; the master copy stays float32).
+template <bool FIXED, bool ZERO, bool SHADOW>
 __global__ void __launch_bounds__(256) adam_ex_kernel(float* __restrict__ p, void* __restrict__ gv, float* __restrict__ m,
                                                       float* __restrict__ v, int64_t count, float lr, float b1, float b2,
-                                                      float eps, float c1, float c2, float gscale) {
+                                                      float eps, float c1, float c2, float gscale, _Float16* __restrict__ ph) {
   float* gf = static_cast<float*>(gv);
   long long* gi64 = static_cast<long long*>(gv);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
@@ -41,7 +43,9 @@ __global__ void __launch_bounds__(256) adam_ex_kernel(float* __restrict__ p, voi
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    p[i] = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+    const float pn = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+    p[i] = pn;
+    if (SHADOW) ph[i] = (_Float16)pn;
   }
 }
 
@@ -49,9 +53,9 @@ __global__ void __launch_bounds__(256) adam_ex_kernel(float* __restrict__ p, voi
 
 using namespace nerf;
 
-extern "C" int nerf_adam_step_ex(float* params, void* grads, float* m, float* v, int64_t count, float lr, float beta1,
-                                 float beta2, float eps, int bias_correction, int step, float grad_scale, int grads_fixed_point,
-                                 int zero_grads, void* stream) {
+extern "C" int nerf_adam_step_shadow(float* params, void* grads, float* m, float* v, int64_t count, float lr, float beta1,
+                                     float beta2, float eps, int bias_correction, int step, float grad_scale, int grads_fixed_point,
+                                     int zero_grads, void* params_half, void* stream) {
   NERF_REQUIRE(params && grads && m && v, NERF_E_NULL, "nerf_adam_step_ex: NULL pointer");
   NERF_REQUIRE(count > 0, NERF_E_SHAPE, "nerf_adam_step_ex: count must be > 0");
   float c1 = 1.0f, c2 = 1.0f;
@@ -62,11 +66,21 @@ extern "C" int nerf_adam_step_ex(float* params, void* grads, float* m, float* v,
   }
   const dim3 g(grid_for(count, 256)), b(256);
   auto s = as_stream(stream);
-#define AX(FX, ZR) hipLaunchKernelGGL((adam_ex_kernel<FX, ZR>), g, b, 0, s, params, grads, m, v, count, lr, beta1, beta2, eps, c1, c2, grad_scale)
-  if (grads_fixed_point) { if (zero_grads) AX(true, true); else AX(true, false); }
-  else { if (zero_grads) AX(false, true); else AX(false, false); }
+  _Float16* ph = static_cast<_Float16*>(params_half);
+#define AX(FX, ZR, SH) hipLaunchKernelGGL((adam_ex_kernel<FX, ZR, SH>), g, b, 0, s, params, grads, m, v, count, lr, beta1, beta2, eps, c1, c2, grad_scale, ph)
+#define AY(FX, ZR) do { if (ph) AX(FX, ZR, true); else AX(FX, ZR, false); } while (0)
+  if (grads_fixed_point) { if (zero_grads) AY(true, true); else AY(true, false); }
+  else { if (zero_grads) AY(false, true); else AY(false, false); }
+#undef AY
 #undef AX
   return check_launch("nerf_adam_step_ex");
+}
+
+extern "C" int nerf_adam_step_ex(float* params, void* grads, float* m, float* v, int64_t count, float lr, float beta1,
+                                 float beta2, float eps, int bias_correction, int step, float grad_scale, int grads_fixed_point,
+                                 int zero_grads, void* stream) {
+  return nerf_adam_step_shadow(params, grads, m, v, count, lr, beta1, beta2, eps, bias_correction, step, grad_scale,
+                               grads_fixed_point, zero_grads, nullptr, stream);
 }
 
 extern "C" int nerf_adam_step(float* params, const float* grads, float* m, float* v, int64_t count, float lr,

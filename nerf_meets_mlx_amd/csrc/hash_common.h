@@ -75,6 +75,15 @@ __device__ __forceinline__ FeatVec<F> load_entry(const float* __restrict__ tb, u
   return r;
 }
 
+// the same entry from the fp16 shadow image of an F = 2 table (one 4-byte load per corner instead of 8 bytes)
+__device__ __forceinline__ FeatVec<2> load_entry_h(const uint32_t* __restrict__ tb, uint32_t i) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const h2_t t = __builtin_bit_cast(h2_t, tb[i]);
+  FeatVec<2> r;
+  r.v[0] = (float)t[0]; r.v[1] = (float)t[1];
+  return r;
+}
+
 struct Corners { uint32_t i[8]; float ox, oy, oz; };
 // reference corner numbering: 0=(c,c,c) 1=(c,f,c) 2=(f,f,c) 3=(f,c,c) 4=(c,c,f) 5=(c,f,f) 6=(f,f,f) 7=(f,c,f)
 __device__ __forceinline__ Corners corners_of(float px, float py, float pz, float r, uint32_t mask) {
@@ -112,10 +121,26 @@ __device__ __forceinline__ void point_of(const PointSrc& ps, int64_t m, float& p
 }
 
 template <int F>
+__device__ __forceinline__ FeatVec<F> trilerp(const FeatVec<F> (&e)[8], const Corners& c);
+
+template <int F>
 __device__ __forceinline__ FeatVec<F> hash_level(const float* __restrict__ tb, const Corners& c) {
-  const FeatVec<F> e0 = load_entry<F>(tb, c.i[0]), e1 = load_entry<F>(tb, c.i[1]), e2 = load_entry<F>(tb, c.i[2]);
-  const FeatVec<F> e3 = load_entry<F>(tb, c.i[3]), e4 = load_entry<F>(tb, c.i[4]), e5 = load_entry<F>(tb, c.i[5]);
-  const FeatVec<F> e6 = load_entry<F>(tb, c.i[6]), e7 = load_entry<F>(tb, c.i[7]);
+  FeatVec<F> e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = load_entry<F>(tb, c.i[k]);
+  return trilerp<F>(e, c);
+}
+// F = 2, entries from the fp16 shadow image; interpolation in float32 as above
+__device__ __forceinline__ FeatVec<2> hash_level_h(const uint32_t* __restrict__ tb, const Corners& c) {
+  FeatVec<2> e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = load_entry_h(tb, c.i[k]);
+  return trilerp<2>(e, c);
+}
+
+template <int F>
+__device__ __forceinline__ FeatVec<F> trilerp(const FeatVec<F> (&e)[8], const Corners& c) {
+  const FeatVec<F>&e0 = e[0], &e1 = e[1], &e2 = e[2], &e3 = e[3], &e4 = e[4], &e5 = e[5], &e6 = e[6], &e7 = e[7];
   const float ox = c.ox, oy = c.oy, oz = c.oz;
   FeatVec<F> r;
 #pragma unroll

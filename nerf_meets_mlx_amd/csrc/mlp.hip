@@ -1388,6 +1388,7 @@ struct SmallArgs {
   int64_t astride, zstride;
   // fused configs[4] query: rows are computed in the kernel from rays / depths / hash tables (16 levels x 2 features)
   const float* rays; const float* z; int n; const float* tables; uint32_t T; ResTab rt; float pos_scale, pos_offset;
+  const uint32_t* tables_h;   // fp16 shadow image of the tables (one 4-byte pair per entry) or nullptr: gathered instead of `tables`
   // ray_major (inference of the fused query only): a 32-sample tile = ONE depth index of 32 ADJACENT RAYS instead of 32
   // consecutive depths of one ray.  Neighbouring pixels' samples at the same depth are 0.0012 apart in the unit cube, so
   // the 32 lanes of a gather instruction fall into the same or adjacent cells at every level below N_l ~ 800 (13 of 16),
@@ -1398,6 +1399,7 @@ struct SmallArgs {
 // B fragments of one sample straight from the hash tables and the view direction: lane (r, h) owns channels
 // kperm(ks, h, j) of k-step ks = levels 8 ks + 4 (j >> 2) + 2 h + ((j & 3) >> 1), feature j & 1, i.e. the two lanes of
 // a sample split the 16 levels between them; SH degree 3 = 16 channels = one k-step.
+template <bool HALF>
 __device__ __forceinline__ void ngp_row_frags(const SmallArgs& a, int64_t m, int h, bf16x8 (&xin)[1][2], bf16x8 (&din)[1][1]) {
   const float* rr = a.rays + (int64_t)((uint64_t)m / (unsigned)a.n) * NERF_RAY_STRIDE;
   const float zv = a.z[m];
@@ -1413,7 +1415,7 @@ __device__ __forceinline__ void ngp_row_frags(const SmallArgs& a, int64_t m, int
       for (int e = 0; e < 2; ++e) {
         const int l = 8 * ks + 4 * q + 2 * h + e;
         const Corners c = corners_of(px, py, pz, a.rt.res[l], mask);
-        const FeatVec<2> fv = hash_level<2>(a.tables + (size_t)l * a.T * 2, c);
+        const FeatVec<2> fv = HALF ? hash_level_h(a.tables_h + (size_t)l * a.T, c) : hash_level<2>(a.tables + (size_t)l * a.T * 2, c);
         xin[0][ks][4 * q + 2 * e] = (__bf16)fv.v[0];
         xin[0][ks][4 * q + 2 * e + 1] = (__bf16)fv.v[1];
       }
@@ -1448,7 +1450,8 @@ __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
     if (m >= a.M) m = a.M - 1;
     bf16x8 xin[ST][2], din[ST][1];
     if (FUSED) {
-      ngp_row_frags(a, m, h, xin, din);
+      if (a.tables_h) ngp_row_frags<true>(a, m, h, xin, din);        // wave-uniform
+      else ngp_row_frags<false>(a, m, h, xin, din);
     } else {
       const float* row = a.x + m * LN::CIN;
       xin[0][0] = row_frag(row, 0, h, LN::CPOS); xin[0][1] = row_frag(row, 1, h, LN::CPOS);
@@ -1811,7 +1814,7 @@ static void small_args(SmallArgs& a, const void* packed) {
   a.bias = reinterpret_cast<const float*>(base + (size_t)(LN::F_PADDED + LN::B_PADDED) * 1024);
   a.x = nullptr; a.d_raw = nullptr; a.out = nullptr; a.d_x = nullptr; a.acts = nullptr; a.dz = nullptr; a.M = 0;
   a.astride = small_astride16(); a.zstride = small_zstride16();
-  a.rays = nullptr; a.z = nullptr; a.n = 1; a.tables = nullptr; a.T = 0; a.pos_scale = 1.0f; a.pos_offset = 0.0f;
+  a.rays = nullptr; a.z = nullptr; a.n = 1; a.tables = nullptr; a.tables_h = nullptr; a.T = 0; a.pos_scale = 1.0f; a.pos_offset = 0.0f;
   a.ray_major = 0; a.B = 0;
 }
 
@@ -2063,10 +2066,10 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astr, zstr, grads, s, split);
 }
 
-extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
-                                    int64_t B, int n, const float* tables, int L, int log2_T, int F,
-                                    const int* resolutions_host, int sh_degree, float pos_scale, float pos_offset,
-                                    float* raw, void* acts, void* stream) {
+extern "C" int nerf_ngp_query_fused_h(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
+                                      int64_t B, int n, const float* tables, const void* tables_half, int L, int log2_T, int F,
+                                      const int* resolutions_host, int sh_degree, float pos_scale, float pos_offset,
+                                      float* raw, void* acts, void* stream) {
   NERF_REQUIRE(arch_kind(arch) == 2, NERF_E_UNSUPPORTED, "nerf_ngp_query_fused: needs the (2x64, in 32+16) model");
   NERF_REQUIRE(L == 16 && F == 2 && sh_degree == 3, NERF_E_UNSUPPORTED,
                "nerf_ngp_query_fused: fused rows exist for 16 levels x 2 features + SH degree 3 (use nerf_ngp_encode + nerf_mlp_forward otherwise)");
@@ -2078,6 +2081,7 @@ extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packe
   SmallArgs a;
   small_args(a, packed);
   a.out = raw; a.acts = acts; a.M = M; a.rays = rays; a.z = z; a.n = n; a.tables = tables; a.T = 1u << log2_T;
+  a.tables_h = static_cast<const uint32_t*>(tables_half);
   a.pos_scale = pos_scale; a.pos_offset = pos_offset;
   for (int l = 0; l < 32; ++l) a.rt.res[l] = l < L ? (float)resolutions_host[l] : 0.0f;
   a.B = B;
@@ -2087,6 +2091,14 @@ extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packe
   if (acts) hipLaunchKernelGGL((mlp_small_fwd_kernel<true, true>), g, b, LN::LDS_BYTES, as_stream(stream), a);
   else hipLaunchKernelGGL((mlp_small_fwd_kernel<false, true>), g, b, LN::LDS_BYTES, as_stream(stream), a);
   return check_launch("nerf_ngp_query_fused");
+}
+
+extern "C" int nerf_ngp_query_fused(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
+                                    int64_t B, int n, const float* tables, int L, int log2_T, int F,
+                                    const int* resolutions_host, int sh_degree, float pos_scale, float pos_offset,
+                                    float* raw, void* acts, void* stream) {
+  return nerf_ngp_query_fused_h(arch, packed, rays, z, B, n, tables, nullptr, L, log2_T, F, resolutions_host, sh_degree, pos_scale,
+                                pos_offset, raw, acts, stream);
 }
 
 extern "C" int nerf_mlp_backward(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,

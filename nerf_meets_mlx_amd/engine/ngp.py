@@ -33,17 +33,34 @@ from .trainer import Trainer
 class _Flat:
     """Adam-compatible view of a flat trainable buffer (the hash tables)."""
 
-    def __init__(self, params: torch.Tensor, grads: torch.Tensor):
+    def __init__(self, params: torch.Tensor, grads: torch.Tensor, half: bool = False):
         self.params, self.grads, self.n_params = params.view(-1), grads.view(-1), params.numel()     # grads: float32 or int64 fixed point
         self.name = "tables"
+        # fp16 shadow image of the tables for the forward gathers (4 instead of 8 bytes per entry pair): written by the Adam
+        # pass that updates the float32 master (`nerf_adam_step_shadow`), rebuilt from the master whenever somebody else wrote it
+        self.half = torch.empty(self.n_params, dtype=torch.float16, device=params.device) if half else None
+        self._half_version = -1              # params._version at which the shadow is known to equal fp16(params); -1: stale
 
-    def mark_updated(self):
-        pass
+    def mark_updated(self, shadow_written: bool = False):
+        """Called by Adam after it wrote the master through raw pointers (no torch version bump): with shadow_written it
+        wrote EVERY shadow entry in the same pass, so the shadow is current; otherwise it is stale."""
+        self._half_version = self.params._version if shadow_written else -1
+
+    def shadow(self) -> Optional[torch.Tensor]:
+        """The fp16 image, current with the float32 master (None when the model was built without one).  Rebuilt by one
+        conversion pass after construction, load_flat, or a torch in-place edit of the tables (version counter)."""
+        if self.half is None:
+            return None
+        if self._half_version != self.params._version:
+            self.half.copy_(self.params)
+            self._half_version = self.params._version
+        return self.half
 
     def load_flat(self, flat: torch.Tensor):
         assert flat.numel() == self.n_params
         with torch.no_grad():
             self.params.copy_(flat.to(self.params.device, torch.float32).reshape(-1))
+        self._half_version = -1
 
 
 class HashNeRF:
@@ -51,8 +68,10 @@ class HashNeRF:
 
     def __init__(self, device="cuda", seed: int = 0, n_levels: int = 16, min_res: int = 16, max_res: int = 2048,
                  n_features_per_level: int = 2, log2_hashmap_size: int = 19, hash_init_scale: float = 1e-4,
-                 bound: Optional[float] = 1.5, deterministic: bool = True, level_groups: int = 4):
-        """bound: half-extent of the scene box that is mapped onto the grid's unit cube before hashing
+                 bound: Optional[float] = 1.5, deterministic: bool = True, level_groups: int = 4, half_tables: bool = True):
+        """half_tables: the fused query gathers from an fp16 shadow image of the tables (half the gather bytes; float32 master,
+        float32 interpolation; the MLP rounds the interpolated features to bf16 anyway) -- SURVEY 8(d)'s 512 B per sample.
+        bound: half-extent of the scene box that is mapped onto the grid's unit cube before hashing
         (x' = (x + bound) / (2 bound)), so that N_l is the level's resolution ACROSS the scene (without it the reference's
         x * N_l sees world units: 3 x finer cells, and a 24-view run memorises its training rays: held-out PSNR 13.8 dB
         at a training loss of 1e-3).  None = world coordinates, the bare reference formula."""
@@ -69,7 +88,7 @@ class HashNeRF:
         self.deterministic = bool(deterministic)
         if self.deterministic:
             self.enc.grad = torch.zeros(self.enc.tables.shape, dtype=torch.int64, device=self.enc.tables.device)
-        self.table = _Flat(self.enc.tables, self.enc.grad)
+        self.table = _Flat(self.enc.tables, self.enc.grad, half=bool(half_tables) and n_features_per_level == 2)
         # True while the accumulator is known to hold zeros (fresh, or consumed-and-cleared by nerf_adam_step_ex); any
         # scatter makes it dirty.  NGPTrainer.train_step only skips the clear when this says so: a public backward() call,
         # or a step that raised between the scatter and Adam, leaves a gradient behind that must not be added to the next one.
@@ -121,10 +140,10 @@ class HashNeRF:
         if train:
             acts = m._begin_train_pass(B * n)
             self._pts, self._rz = None, (rays, z)
-        N.check(N.lib().nerf_ngp_query_fused(C.byref(m.arch), N.ptr(m.packed()), N.ptr(rays), N.ptr(z), B, n,
-                                             N.ptr(e.tables), e.n_levels, e.log2_hashmap_size, e.n_features_per_level,
-                                             e._res_c, 3, self.pos_scale, self.pos_offset, N.ptr(raw), N.ptr(acts),
-                                             N.stream()))
+        N.check(N.lib().nerf_ngp_query_fused_h(C.byref(m.arch), N.ptr(m.packed()), N.ptr(rays), N.ptr(z), B, n,
+                                               N.ptr(e.tables), N.ptr(self.table.shadow()), e.n_levels, e.log2_hashmap_size,
+                                               e.n_features_per_level, e._res_c, 3, self.pos_scale, self.pos_offset,
+                                               N.ptr(raw), N.ptr(acts), N.stream()))
         return raw
 
     def table_grad(self) -> torch.Tensor:
@@ -171,7 +190,7 @@ class NGPTrainer(Trainer):
 
     def __init__(self, images, poses, K, near: float = 2.0, far: float = 6.0, N_rand: int = 4096,
                  n_depth_samples: int = 64, lrate: float = 5e-4, lrate_decay: int = 500, white_bkgd: bool = True,
-                 seed: int = 0, device="cuda", chunk: int = 1024 * 32, **hash_kw):
+                 seed: int = 0, device="cuda", chunk: int = 1024 * 32, table_sync: str = "shard", **hash_kw):
         super().__init__(images, poses, K, near=near, far=far, N_rand=N_rand, n_depth_samples=n_depth_samples,
                          N_importance=0, lrate=lrate, lrate_decay=lrate_decay, white_bkgd=white_bkgd, ref_quirks=True,
                          seed=seed, device=device, chunk=chunk)
@@ -184,6 +203,19 @@ class NGPTrainer(Trainer):
         # the reference's 5e-4 (at 2e-3 both this trainer and the fp32 oracle collapse to sigma < 0 within 200 iterations).
         self.opt = Adam(lrate, betas=(0.9, 0.99), eps=1e-8, bias_correction=True, shared_state=False)
         self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        # How the table gradient is combined across ranks (world_size > 1):
+        #   "allreduce": every level group's accumulator slice is sum-all-reduced, every rank steps all 16.8 M entries
+        #                (int64 accumulators: 134 MB on the wire twice per step);
+        #   "shard"    : reduce-scatter of the accumulators (each rank receives the sum of ITS 1/W of every level group), Adam on
+        #                the owned shards only, all-gather of the updated float32 tables: 134 (W-1)/W + 67 (W-1)/W MB instead of
+        #                2 x 134 (W-1)/W, a W-th of the Adam work, and exact integer sums as before (bit-identical tables on all
+        #                ranks, run to run, and identical to the all-reduce schedule).  Adam moments are sharded with the
+        #                parameters: state_dict() gathers them (a collective: every rank must call it).
+        if table_sync not in ("shard", "allreduce"):
+            raise ValueError("NGPTrainer: table_sync must be 'shard' or 'allreduce'")
+        per_group = [(hi - lo) * self.field.enc.hash_table_size * self.field.enc.n_features_per_level for lo, hi in self.field.level_groups]
+        self.table_sync = table_sync if (self.world > 1 and all(n % self.world == 0 for n in per_group)) else "allreduce"
+        self._rs_bufs = None
 
     def train_step(self, rays=None, target=None, u=None) -> Dict[str, torch.Tensor]:
         if rays is None:
@@ -193,6 +225,7 @@ class NGPTrainer(Trainer):
         raw = self.field.query(rays, z, train=True)
         loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, self.white_bkgd)
         pending, mlp_work = [], []
+        shard = self.world > 1 and self.table_sync == "shard"
         if self.world > 1:
             # Collectives of one process group run in issue order, so the small MLP gradient goes FIRST (it is complete
             # before the scatters start), then each level group's slice of the table gradient as soon as its scatter is
@@ -208,7 +241,22 @@ class NGPTrainer(Trainer):
                 with torch.cuda.stream(self._comm):
                     return torch.distributed.all_reduce(t, async_op=True)
             self.field.on_mlp_grads = lambda g: mlp_work.append(on_comm(g))
-            self.field.on_group_done = lambda lo, hi: pending.append(on_comm(flat[lo * per_level:hi * per_level]))
+            if shard:
+                if self._rs_bufs is None or self._rs_bufs[0].dtype != flat.dtype:
+                    self._rs_bufs = [torch.empty((hi - lo) * per_level // self.world, dtype=flat.dtype, device=flat.device)
+                                     for lo, hi in self.field.level_groups]
+
+                def on_group(lo, hi):
+                    gi = self.field.level_groups.index((lo, hi))
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._comm.wait_event(ev)
+                    with torch.cuda.stream(self._comm):
+                        pending.append(torch.distributed.reduce_scatter_tensor(self._rs_bufs[gi], flat[lo * per_level:hi * per_level],
+                                                                               async_op=True))
+                self.field.on_group_done = on_group
+            else:
+                self.field.on_group_done = lambda lo, hi: pending.append(on_comm(flat[lo * per_level:hi * per_level]))
         # accumulate (no clear) only when the accumulator is KNOWN to be zero: left so by the previous step's table Adam
         g_mlp, g_tab = self.field.backward(d_raw, accumulate=self.field._grad_clean)
         self.field.on_group_done = self.field.on_mlp_grads = None
@@ -219,7 +267,20 @@ class NGPTrainer(Trainer):
             w.wait()
         if pending:
             torch.cuda.current_stream().wait_stream(self._comm)
-        self._opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world, zero_grads=True)    # reads g, writes 0
+        if shard:
+            # Adam on the owned 1/W of every level group (sums received by the reduce-scatter), then every rank gets the others'
+            # updated entries; the accumulator was consumed by the collectives: clear it (one 134 MB memset, ~30 us)
+            params = self.field.table.params
+            spans = []
+            for (lo, hi), buf in zip(self.field.level_groups, self._rs_bufs):
+                n = buf.numel()
+                spans.append((lo * per_level + self.rank * n, lo * per_level + (self.rank + 1) * n, buf))
+            self._opt.update_spans(self.field.table, spans, grad_scale=1.0 / self.world)
+            flat.zero_()
+            for (lo, hi), (a, b, _) in zip(self.field.level_groups, spans):
+                torch.distributed.all_gather_into_tensor(params[lo * per_level:hi * per_level], params[a:b].clone())
+        else:
+            self._opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world, zero_grads=True)    # reads g, writes 0
         self.field._grad_clean = True
         self.it += 1
         return {"loss_coarse": loss}
@@ -232,6 +293,18 @@ class NGPTrainer(Trainer):
             raw = self.field.query(r, z)
             outs.append(render.composite(raw, z, r, 0.0, self.white_bkgd, need_weights=False)[0])
         return torch.cat(outs, 0)
+
+    def state_dict(self):
+        """With sharded table updates (table_sync "shard", world_size > 1) a rank's Adam moments are current on its own
+        shards only: they are gathered here first -- a COLLECTIVE, every rank must call state_dict() / save() together."""
+        if self.world > 1 and self.table_sync == "shard" and "tables" in self._opt.state:
+            per_level = self.field.enc.hash_table_size * self.field.enc.n_features_per_level
+            for t in self._opt.state["tables"]:
+                for lo, hi in self.field.level_groups:
+                    n = (hi - lo) * per_level // self.world
+                    a = lo * per_level + self.rank * n
+                    torch.distributed.all_gather_into_tensor(t[lo * per_level:hi * per_level], t[a:a + n].clone())
+        return super().state_dict()
 
     def _checkpoint_buffers(self):
         """Trainer.save / load / state_dict / load_state_dict work on these: the 2 x 64 MLP and the hash tables, with

@@ -243,16 +243,38 @@ class Adam:
             self.state[key] = [torch.zeros_like(model.params), torch.zeros_like(model.params)]
         self.step_count[key] = self.step_count.get(key, 0) + 1
         m, v = self.state[key]
-        if zero_grads or g.dtype == torch.int64:
-            N.check(N.lib().nerf_adam_step_ex(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
-                                              float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
-                                              float(self.eps), int(self.bias_correction), self.step_count[key],
-                                              float(grad_scale), int(g.dtype == torch.int64), int(bool(zero_grads)), N.stream()))
+        half = getattr(model, "half", None)                  # fp16 shadow of the parameters (hash tables): written in the same pass
+        if zero_grads or g.dtype == torch.int64 or half is not None:
+            N.check(N.lib().nerf_adam_step_shadow(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
+                                                  float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
+                                                  float(self.eps), int(self.bias_correction), self.step_count[key],
+                                                  float(grad_scale), int(g.dtype == torch.int64), int(bool(zero_grads)),
+                                                  N.ptr(half), N.stream()))
+            if half is not None:
+                model.mark_updated(shadow_written=True)
+                return
         else:
             N.check(N.lib().nerf_adam_step(N.ptr(model.params), N.ptr(g), N.ptr(m), N.ptr(v), model.n_params,
                                            float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
                                            float(self.eps), int(self.bias_correction), self.step_count[key],
                                            float(grad_scale), N.stream()))
+        model.mark_updated()
+
+    def update_spans(self, model, spans, grad_scale: float = 1.0):
+        """ONE optimiser step of `model` applied to the element ranges `spans` = [(lo, hi, grads[hi - lo]), ...] only (the
+        shards of a flat buffer this rank owns: NGPTrainer's reduce-scatter update).  Moments of the other elements are left
+        alone; the step count advances once.  float32 or int64 fixed-point gradients, not cleared."""
+        key = self.key_of(model)
+        if key not in self.state:
+            self.state[key] = [torch.zeros_like(model.params), torch.zeros_like(model.params)]
+        self.step_count[key] = self.step_count.get(key, 0) + 1
+        m, v = self.state[key]
+        for lo, hi, g in spans:
+            assert g.numel() == hi - lo and g.is_contiguous()
+            N.check(N.lib().nerf_adam_step_shadow(N.ptr(model.params[lo:hi]), N.ptr(g), N.ptr(m[lo:hi]), N.ptr(v[lo:hi]), hi - lo,
+                                                  float(self.learning_rate), float(self.betas[0]), float(self.betas[1]),
+                                                  float(self.eps), int(self.bias_correction), self.step_count[key],
+                                                  float(grad_scale), int(g.dtype == torch.int64), 0, None, N.stream()))
         model.mark_updated()
 
     def state_dict(self) -> Dict[str, object]:

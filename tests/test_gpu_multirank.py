@@ -106,10 +106,11 @@ def _ngp_worker(rank, world, port, q):
     torch.cuda.set_device(0)
     parallel.init_from_env(backend="gloo")
     imgs, poses, _, _, K = synthetic.make_dataset(16, 16, 3, seed=0, device="cuda")
-    res = []
-    for det in (True, False):
+    res, finals = [], {}
+    for det, sync in ((True, "shard"), (True, "allreduce"), (False, "shard"), (False, "allreduce")):
         tr = NGPTrainer(imgs, poses, K, N_rand=64, n_depth_samples=64, seed=7, device="cuda", log2_hashmap_size=12,
-                        deterministic=det, level_groups=4)
+                        deterministic=det, level_groups=4, table_sync=sync)
+        assert tr.table_sync == sync
         t0 = tr.field.enc.tables.clone()
         for _ in range(3):
             out = tr.train_step()
@@ -121,15 +122,29 @@ def _ngp_worker(rank, world, port, q):
         same = all(torch.equal(ts[0], t) for t in ts) and all(torch.equal(ms[0], m) for m in ms)
         moved = not torch.equal(t0, tr.field.enc.tables)
         cleared = float(tr.field.enc.grad.abs().max()) == 0.0
-        res.append((det, same, moved, cleared, float(out["loss_coarse"])))
+        # the fp16 shadow the next query gathers from follows the gathered master tables
+        shadow_ok = torch.equal(tr.field.table.shadow(), tr.field.enc.tables.view(-1).half())
+        # state_dict() is a collective in shard mode: afterwards every rank holds the same, complete Adam moments
+        sd = tr.state_dict()
+        mv = sd["adam"]["state"]["tables"][0].to("cuda")
+        mvs = [torch.zeros_like(mv) for _ in range(world)]
+        dist.all_gather(mvs, mv)
+        same = same and all(torch.equal(mvs[0], t) for t in mvs) and float(mv.abs().max()) > 0
+        finals[(det, sync)] = (tr.field.enc.tables.clone(), mv)
+        res.append((det, same and shadow_ok, moved, cleared, float(out["loss_coarse"])))
+    # exact integer sums: the sharded schedule lands on the all-reduce schedule's tables and moments bit for bit
+    eq = torch.equal(finals[(True, "shard")][0], finals[(True, "allreduce")][0]) and torch.equal(finals[(True, "shard")][1], finals[(True, "allreduce")][1])
+    res.append((True, eq, True, True, 0.0))
     q.put((rank, res))
     dist.destroy_process_group()
 
 
 def test_ngp_two_ranks_grouped_table_allreduce_keeps_tables_identical():
-    """configs[4] with world_size 2: the table gradient (float32, or int64 fixed point in deterministic mode) is
-    all-reduced level group by level group on the comm stream while the next group's scatter and the MLP step run; after
-    every step both ranks hold bit-identical tables and MLP weights, and the accumulators are cleared by the Adam pass."""
+    """configs[4] with world_size 2: the table gradient (float32, or int64 fixed point in deterministic mode) is combined level
+    group by level group on the comm stream while the next group's scatter and the MLP step run -- by reduce-scatter + Adam on
+    the owned shards + all-gather of the updated tables (`table_sync="shard"`, the default) or by all-reduce; after every step
+    both ranks hold bit-identical tables and MLP weights, the accumulators are cleared, the fp16 shadow follows, state_dict()
+    gathers the sharded Adam moments, and in deterministic mode the two schedules give the same tables and moments bit for bit."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

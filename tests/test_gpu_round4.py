@@ -292,3 +292,33 @@ def test_checkpoint_from_before_the_stateless_streams_is_refused_unless_opted_in
     assert torch.equal(torch.rand(4, device=DEV, generator=c.gen), torch.rand(4, device=DEV, generator=Trainer(imgs, poses, K, N_rand=32, seed=11, device=DEV).gen))
     path = a.save(str(tmp_path / "ck"))
     assert c.load(path) == 1
+
+
+# ------------------------------------------------------------------------------------------------ a22: fp16 shadow tables
+def test_ngp_half_shadow_tables_follow_the_float32_master():
+    """configs[4]: the fused query gathers from an fp16 shadow image of the hash tables (4 bytes per entry pair, SURVEY 8(d)'s
+    512 B of gathers per sample) that the tables' Adam pass writes next to the float32 master.  (1) shadow == fp16(master)
+    after construction, after training steps, after a torch in-place edit and after load_flat; (2) the query through the
+    shadow agrees with the query through the float32 tables to fp16 resolution of the table values (the MLP rounds the
+    interpolated features to bf16 = 2^-9 anyway); (3) master tables and MLP of a run with and without the shadow stay
+    within the tolerance the bf16 arithmetic of the step allows."""
+    from nerf_meets_mlx_amd import sampling
+    a, b = _ngp(True, half_tables=True), _ngp(True, half_tables=False)
+    assert a.field.table.half is not None and b.field.table.half is None
+    rays, target = a.sample_batch()
+    z = sampling.sample_coarse(rays, 64)
+    with torch.no_grad():                                   # values large enough to matter: the 1e-4 initialisation is all fp16 denormals
+        a.field.enc.tables.mul_(3000.0); b.field.enc.tables.mul_(3000.0)
+    ra, rb = a.field.query(rays, z), b.field.query(rays, z)
+    assert torch.equal(a.field.table.half, a.field.enc.tables.view(-1).half())
+    sc = float(rb.abs().max())
+    assert float((ra - rb).abs().max()) <= 4e-3 * sc, float((ra - rb).abs().max()) / sc
+    assert torch.equal(b.field.query(rays, z), rb)
+    for _ in range(3):
+        la, lb = a.train_step(), b.train_step()
+        assert torch.equal(a.field.table.half, a.field.enc.tables.view(-1).half())      # written by nerf_adam_step_shadow
+        assert abs(float(la["loss_coarse"]) - float(lb["loss_coarse"])) <= 2e-2 * float(lb["loss_coarse"])
+    flat = b.field.enc.tables.view(-1).clone()
+    a.field.table.load_flat(flat)
+    a.field.query(rays, z)
+    assert torch.equal(a.field.table.half, flat.half())

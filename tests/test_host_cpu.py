@@ -49,6 +49,12 @@ def test_host_argument_validation_without_gpu():
     assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == bf16_image
     assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 63, 27, 4, 1, 4, 0))) == bf16_image     # 0 = default = 16
     assert lib.nerf_mlp_packed_bytes(C.byref(arch32)) == bf16_image + fp32_image
+    arch22 = _native.MlpArch(8, 256, 63, 27, 4, 1, 4, 22)               # float32 tolerance on the 16-bit matrix pipe (round 4)
+    f22_image = 2368 * 1024 + 2496 * 4                                   # split-fp16 (hi, lo) forward stream + bias slots
+    s16_image = (2368 + 2208) * 1024                                     # split-bf16 (hi, lo) forward + transposed streams
+    assert lib.nerf_mlp_packed_bytes(C.byref(arch22)) == bf16_image + f22_image + s16_image
+    assert lib.nerf_mlp_acts_bytes(C.byref(arch22), 65) == 8 * 325 * 1024        # hi blocks | lo blocks | sign-bit words
+    assert lib.nerf_mlp_dz_bytes(C.byref(arch22), 65) == 8 * 308 * 1024 + 512 * (64 * 1024 + 256) * 4
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
     assert lib.nerf_mlp_acts_bytes(C.byref(arch32), 65) == 3 * 2592 * 128         # fp32 stores: rows x 32 floats per tile (2528 activation rows + 64 of ReLU sign bits)
     assert lib.nerf_mlp_dz_bytes(C.byref(arch32), 65) == 3 * 2496 * 128 + 2048 * (4096 + 64) * 4      # + split-K partial blocks of dW
