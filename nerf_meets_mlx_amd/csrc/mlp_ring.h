@@ -43,10 +43,22 @@ __device__ __forceinline__ void dma_frag(const void* gsrc_lane, unsigned lds_add
 }
 // same with a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (no 64-bit VGPR address per fragment,
 // which hipcc would otherwise hoist out of persistent loops and spill)
+// NERF_DMA_CLOBBER_M0 (per translation unit; on for the one-wave-per-SIMD split kernels, where every scalar instruction of the
+// 600 DMAs a wave issues per pass is exposed issue time): M0 is written and left, declared as a clobber, instead of saved and
+// restored -- 2 of the 7 scalar instructions per DMA.  Valid while nothing compiler-generated in the kernel reads M0 (these
+// kernels have no LDS-DMA builtins, no register-indexed moves, no messages: tools/check_m0.py scans the ISA of the build).
+#ifndef NERF_DMA_CLOBBER_M0
+#define NERF_DMA_CLOBBER_M0 0
+#endif
 __device__ __forceinline__ void dma_frag_s(const void* gbase_uniform, unsigned lane_off, unsigned lds_addr) {
+#if NERF_DMA_CLOBBER_M0
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(lane_off), "s"(gbase_uniform), "s"(lds_addr) : "memory", "m0");
+#else
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(lane_off), "s"(gbase_uniform), "s"(lds_addr) : "memory");
+#endif
 }
 // non-temporal form for bytes that are read exactly once (the dW kernel's dZ / activation stream)
 __device__ __forceinline__ void dma_frag_nt(const void* gsrc_lane, unsigned lds_addr) {

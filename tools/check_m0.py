@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Scan gfx950 ISA for uses of M0 other than the LDS-DMA statements of csrc/mlp_ring.h (`s_mov_b32 m0, <sgpr>` directly in
+front of a `global_load_lds_*`).  The split-precision kernels are built with NERF_DMA_CLOBBER_M0: their asm writes M0 and does
+not restore it, which is valid only while nothing the COMPILER generated reads M0 or expects a value it put there.
+    python tools/check_m0.py build/mlp22-hip-amdgcn-amd-amdhsa-gfx950.s [--kernels substr ...]"""
+import argparse
+import re
+import sys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("asm")
+    ap.add_argument("--kernels", nargs="*", default=[])
+    a = ap.parse_args()
+    text = open(a.asm).read()
+    bad, seen = 0, 0
+    for m in re.finditer(r"^(_Z[^\n:]*):[^\n]*\n", text, re.M):
+        name = m.group(1)
+        if a.kernels and not any(k in name for k in a.kernels):
+            continue
+        end = text.find(".Lfunc_end", m.end())
+        body = [ln.split(";")[0].strip() for ln in text[m.end():end].split("\n")]
+        body = [ln for ln in body if ln and not ln.startswith(".")]
+        seen += 1
+        ours = other = 0
+        for i, ln in enumerate(body):
+            if not re.search(r"\bm0\b", ln):
+                continue
+            nxt = [x for x in body[i + 1:i + 4]]
+            if re.match(r"s_mov_b32 m0, s\d+$", ln) and any(x.startswith("global_load_lds") for x in nxt):
+                ours += 1
+            else:
+                other += 1
+                if other <= 5:
+                    print(f"    {name}: compiler-side M0 use: {ln}")
+        print(f"{name}: {ours} LDS-DMA M0 writes, {other} other M0 uses")
+        bad += other
+    if not seen:
+        print("no kernel matched", file=sys.stderr)
+        return 2
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

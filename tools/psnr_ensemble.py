@@ -125,14 +125,14 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
     mk = lambda prec: Trainer(imgs[:-a.test_views], poses[:-a.test_views], K, N_rand=a.n_rand, n_depth_samples=64,
                               N_importance=a.n_importance, seed=seed, device=dev, lrate_decay=a.lrate_decay,
                               ref_quirks=quirks, precision=prec)
-    arms = {"bf16": mk(16), "fp32": mk(32)}
+    arms = {"bf16": mk(getattr(a, "lead_precision", 16)), "fp32": mk(32)}        # key "bf16" = the lead arm (renamed on output when it is not 16)
     assert torch.equal(arms["bf16"].coarse.params, arms["fp32"].coarse.params)
     if getattr(a, "null_arm", False):
         # NULL arm: the SAME bf16 arithmetic, only the fp32 summation ORDER of the weight-gradient reduction differs (the
         # dW kernel's split-K count, an A/B knob: 240 workgroups instead of one per CU) -- relative differences of 1e-7 per
         # gradient.  delta(bf16b - bf16) is what "two runs of one arithmetic" look like under this training recipe: the
         # yardstick for the bf16 - fp32 differences.
-        arms["bf16b"] = mk(16)
+        arms["bf16b"] = mk(getattr(a, "lead_precision", 16))
     dead = {k: DeadTracker() for k in arms}
     ot = None
     if bridge:
@@ -266,15 +266,20 @@ def main():
                     "checkpoint's delta is then the drift of ONE interval from a common state (short-horizon bias estimator)")
     ap.add_argument("--eval-pixels", type=int, default=0, help="evaluate the held-out PSNR on this many fixed pixels per test view (0: all)")
     ap.add_argument("--out", default="", help="also append every line to this file")
+    ap.add_argument("--lead-precision", type=int, default=16, choices=[16, 22], help="precision of the lead arm (and of the null arm): 16 = "
+                    "bf16 operands; 22 = the float32-tolerance mode on the 16-bit matrix pipe (split-bf16 training, split-fp16 rendering); "
+                    "with 22 every 'bf16' in the output keys reads 'p22'")
     a = ap.parse_args()
     fp = open(a.out, "a") if a.out else None
 
     def emit(line):
+        if a.lead_precision != 16:
+            line = line.replace("bf16", f"p{a.lead_precision}")
         print(line, flush=True)
         if fp:
             fp.write(line + "\n"); fp.flush()
     seeds = [int(x) for x in a.seed_list.split(",") if x] if a.seed_list else alive_seeds(a.seeds, not a.no_quirks, a.seed_start)
-    emit(json.dumps({"config": vars(a), "seeds": seeds, "arms": {"bf16": "Trainer(precision=16)", "fp32": "Trainer(precision=32)"}}))
+    emit(json.dumps({"config": vars(a), "seeds": seeds, "arms": {"bf16": f"Trainer(precision={a.lead_precision})", "fp32": "Trainer(precision=32)"}}))
     if a.bridge > 0:
         brecs = []
         for sd in seeds[:a.bridge]:
