@@ -59,3 +59,21 @@ def test_fp32_kernels_never_touch_a_register_ahead_of_its_wait(tmp_path):
         assert n_loads > 50, name
         assert bad == [], (name, bad[:3])
     assert seen == 4                                                  # forward (store / no store), chain, dW
+
+
+def test_m0_scanner_accepts_the_ring_statements_and_flags_compiler_uses(tmp_path):
+    """tools/check_m0.py (run by csrc/Makefile on the ISA of the split-precision kernels, which write M0 without restoring
+    it): the ring's `s_mov_b32 m0, sN` + `global_load_lds` pairs pass, any other mention of M0 fails the scan."""
+    import check_m0
+    ok = tmp_path / "ok.s"
+    ok.write_text("_ZN4nerf3f2216mlp22_fwd_kernelILi1EEEvNS_7FwdArgsE: ; @k\n\ts_mov_b32 m0, s12\n\ts_nop 0\n"
+                  "\tglobal_load_lds_dwordx4 v3, s[4:5]\n\tv_mfma_f32_16x16x32_f16 v[0:3], v[4:7], a[0:3], v[0:3]\n.Lfunc_end0:\n")
+    bad = tmp_path / "bad.s"
+    bad.write_text("_ZN4nerf3f2216mlp22_fwd_kernelILi1EEEvNS_7FwdArgsE: ; @k\n\ts_mov_b32 m0, s12\n\ts_nop 0\n"
+                   "\tglobal_load_lds_dwordx4 v3, s[4:5]\n\ts_mov_b32 s9, m0\n\tv_movrels_b32 v1, v2\n.Lfunc_end0:\n")
+    sys.argv = ["check_m0.py", str(ok), "--kernels", "fwd_kernel"]
+    assert check_m0.main() == 0
+    sys.argv = ["check_m0.py", str(bad), "--kernels", "fwd_kernel"]
+    assert check_m0.main() == 1
+    sys.argv = ["check_m0.py", str(ok), "--kernels", "no_such_kernel"]
+    assert check_m0.main() == 2

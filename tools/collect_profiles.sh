@@ -21,6 +21,12 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write --
 echo write done
 mkdir -p $O/summary
 python tools/summarize_rocprof.py --round $R --stats $O/prof_bench --fetch $O/pmc_fetch --write $O/pmc_write --out $O/summary
+# the declared reduced-precision bf16 mode of the same step: kernel stats only (continuity with rounds 1-3)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench_bf16 -- python3 bench.py --precision 16 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs > $O/bench_prof_bf16.log 2>&1
+mkdir -p $O/summary_bf16
+python tools/summarize_rocprof.py --round ${R}_bf16 --stats $O/prof_bench_bf16 --out $O/summary_bf16
+find $O/prof_bench_bf16 -type f ! -name "*_kernel_stats.csv" -size +4M -delete
+echo bf16 stats done
 du -sh $O/prof_bench $O/pmc_fetch $O/pmc_write
 # raw traces stay on the box unless small: keep the per-kernel stats file, drop the rest
 find $O/prof_bench $O/pmc_fetch $O/pmc_write -type f ! -name "*_kernel_stats.csv" -size +4M -delete
