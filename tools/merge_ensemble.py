@@ -19,22 +19,34 @@ def main():
         print(__doc__)
         return 2
     out, ins = sys.argv[1], sys.argv[2:]
-    rows, deads, cfg, seeds = [], {}, None, []
+    rows, deads, cfg, seeds, arms, lead = [], {}, None, [], None, 16
     for p in ins:
         for ln in open(p):
+            # a lead arm other than bf16 (psnr_ensemble.py --lead-precision 22) is written with 'p22' in place of 'bf16':
+            # merged under the tool's internal key and renamed again on output
+            if '"lead_precision": 22' in ln:
+                lead = 22
+            ln = ln.replace("p22", "bf16") if lead == 22 else ln
             r = json.loads(ln)
             if "config" in r:
                 cfg = cfg or r["config"]
+                arms = arms or r.get("arms")
                 seeds += r["seeds"]
             elif "dead_sigma" in r and not r.get("bridge"):
                 deads[r["seed"]] = r["dead_sigma"]
             elif "iter" in r and "seed" in r and "psnr_oracle" not in r:
                 rows.append(r)
     done = sorted({r["seed"] for r in rows})
-    with open(out, "w") as fp:
+    class _Out:
+        def __init__(self, f):
+            self.f = f
+        def write(self, t):
+            self.f.write(t.replace("bf16", "p22") if lead == 22 else t)
+    with open(out, "w") as raw_fp:
+        fp = _Out(raw_fp)
         keep = {k: cfg[k] for k in ("hw", "n_rand", "iters", "every", "views", "test_views", "n_importance", "lrate_decay", "no_quirks")}
         fp.write(json.dumps({"merged_from": [os.path.basename(p) for p in ins], "config": keep, "seeds": done,
-                             "arms": {"bf16": "Trainer(precision=16)", "fp32": "Trainer(precision=32)"}}) + "\n")
+                             "arms": arms or {"bf16": "Trainer(precision=16)", "fp32": "Trainer(precision=32)"}}) + "\n")
         for r in sorted(rows, key=lambda r: (r["seed"], r["iter"])):
             fp.write(json.dumps(r) + "\n")
         for sd in done:
