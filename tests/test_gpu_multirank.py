@@ -56,6 +56,13 @@ def _worker(rank, world, port, q, tmp):
     overlap_ok = (full._comm is not None and ser._comm is None
                   and torch.equal(full.fine.params, ser.fine.params) and torch.equal(full.coarse.params, ser.coarse.params)
                   and all(torch.equal(a, b) for a, b in zip(full.opt.state["shared"], ser.opt.state["shared"])))
+    # the bench's headline mode under two ranks: same collectives, split-precision kernels -> identical weights on all ranks
+    t22 = Trainer(imgs, poses, K, N_rand=64, n_depth_samples=64, N_importance=128, seed=4, device="cuda", precision=22)
+    for _ in range(2):
+        t22.train_step()
+    p22 = [torch.zeros_like(t22.fine.params) for _ in range(world)]
+    dist.all_gather(p22, t22.fine.params)
+    overlap_ok = overlap_ok and all(torch.equal(p22[0], t) for t in p22) and bool(torch.isfinite(p22[0]).all())
     part = mk()
     for _ in range(2):
         part.train_step()

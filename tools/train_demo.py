@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--every", type=int, default=500)
     ap.add_argument("--n-rand", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=-1)
+    ap.add_argument("--precision", type=int, default=16, choices=[16, 22, 32], help="8 x 256 model only (config nerf)")
     a = ap.parse_args()
     dev = "cuda"
     H = W = a.hw
@@ -31,11 +32,13 @@ def main():
     test_imgs, test_poses = imgs[-2:], poses[-2:]
     if a.config == "nerf":
         seed = 4 if a.seed < 0 else a.seed                  # coarse 4 / fine 5 start alive
-        tr = Trainer(imgs[:-2], poses[:-2], K, N_rand=a.n_rand, n_depth_samples=64, N_importance=128, seed=seed, device=dev)
+        tr = Trainer(imgs[:-2], poses[:-2], K, N_rand=a.n_rand, n_depth_samples=64, N_importance=128, seed=seed, device=dev,
+                     precision=a.precision)
     else:
         seed = 7 if a.seed < 0 else a.seed
         tr = NGPTrainer(imgs[:-2], poses[:-2], K, N_rand=a.n_rand, n_depth_samples=64, seed=seed, device=dev)
-    print(json.dumps({"config": a.config, "hw": H, "views": a.views, "n_rand": a.n_rand, "seed": seed}), flush=True)
+    print(json.dumps({"config": a.config, "hw": H, "views": a.views, "n_rand": a.n_rand, "seed": seed,
+                      "precision": a.precision if a.config == "nerf" else 16}), flush=True)
     psnr = lambda: float(np.mean([tr.psnr(p[:3, :4].cpu().numpy(), im) for im, p in zip(test_imgs, test_poses)]))
     print(json.dumps({"iter": 0, "psnr": psnr()}), flush=True)
     torch.cuda.synchronize()
