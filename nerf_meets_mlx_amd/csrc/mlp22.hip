@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64 * NW22) mlp22_fwd_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwtiles = (a.M + 31) / 32, nsuper = (nwtiles + NW22 - 1) / NW22;
-  RingW<CHUNKS, F_FRAGS, 4, NW22> ws;
+  RingW<CHUNKS, F_FRAGS, 4, NW22, RING_CHUNK, RING_STAGES, true> ws;      // DMA runs of four (mlp_ring.h)
   ws.wsrc = reinterpret_cast<const char*>(a.wf);
   ws.lane16 = 16 * lane;
   ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));

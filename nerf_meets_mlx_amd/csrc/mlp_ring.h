@@ -71,6 +71,14 @@ __device__ __forceinline__ void dma_frag_nt(const void* gsrc_lane, unsigned lds_
                : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
 #endif
 }
+#if NERF_DMA_CLOBBER_M0
+// follow-up DMA of a run of consecutive fragments: M0 and the source base are the ones the run's first dma_frag_s left behind;
+// the instruction's immediate offset moves BOTH the global and the LDS address (1 KiB per fragment; 13-bit signed: up to 3 KiB)
+template <int OFF>
+__device__ __forceinline__ void dma_frag_next(const void* gbase_uniform, unsigned lane_off) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" :: "v"(lane_off), "s"(gbase_uniform), "n"(OFF) : "memory");
+}
+#endif
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
@@ -99,7 +107,10 @@ extern __shared__ __attribute__((aligned(16))) char ring_smem[];
 // consumed per pass (multiple of RING_GROUP)
 // CHUNK / STAGES: fragments per ring stage and stages (default 32 x 4 = 128 KiB for one 8-wave workgroup per CU; 16 x 4 =
 // 64 KiB lets two independent 4-wave workgroups share a CU, see mlp_fwd_ring_kernel)
-template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES>
+// RUN4 (needs NERF_DMA_CLOBBER_M0 and 8 DMAs per wave and chunk): see issue_one.  Opt-in per kernel: it pays in the two forward
+// kernels of the split-precision modes (-3 % on the split-fp16 forward); in the split-bf16 chain kernel it tipped hipcc's
+// register allocation into scratch (+3 ms), so that one keeps the interleaved shares.
+template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES, bool RUN4 = false>
 struct RingW {
   static constexpr int DPW = CHUNK / NW;               // DMAs per wave per chunk
   static constexpr int STAGE_BYTES = CHUNK * 1024, BIAS_OFF = STAGES * STAGE_BYTES, LDS_BYTES = BIAS_OFF + 2560 * 4;
@@ -112,8 +123,27 @@ struct RingW {
   int woff;                            // ring_pos * STAGE + 16 * lane
   bf16x8 cur[RING_GROUP], nxt[RING_GROUP];
 
-  // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k
+  // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k -- or, with M0-clobbering DMA statements and 8 DMAs per
+  // wave and chunk (the 4-wave rings of the split-precision kernels), the CONSECUTIVE fragments DPW wv + k: a run of four then
+  // shares one M0 write, one hazard nop and one source base, the other three are a bare DMA with an immediate offset (the DMAs of a
+  // chunk are issued in order k = 0..7 and nothing else writes M0 in these kernels: tools/check_m0.py)
+  const char* run_base;                // source base of the current run of four (NERF_DMA_CLOBBER_M0, DPW == 8)
   __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
+#if NERF_DMA_CLOBBER_M0
+    if (RUN4 && DPW == 8) {
+      const int i = wv * DPW + k;
+      switch (k & 3) {
+        case 0:
+          run_base = wsrc + ((int64_t)chunk * CHUNK + i) * 1024;
+          dma_frag_s(run_base, lane16, lds0 + stage * STAGE_BYTES + i * 1024);
+          break;
+        case 1: dma_frag_next<1024>(run_base, lane16); break;
+        case 2: dma_frag_next<2048>(run_base, lane16); break;
+        default: dma_frag_next<3072>(run_base, lane16); break;
+      }
+      return;
+    }
+#endif
     const int i = wv + NW * k;
     dma_frag_s(wsrc + ((int64_t)chunk * CHUNK + i) * 1024, lane16, lds0 + stage * STAGE_BYTES + i * 1024);
   }
@@ -190,7 +220,7 @@ struct RingW {
 };
 
 template <class WS> struct is_ring { static constexpr bool value = false; };
-template <int N, int T, int G, int W, int C, int S> struct is_ring<RingW<N, T, G, W, C, S>> { static constexpr bool value = true; };
+template <int N, int T, int G, int W, int C, int S, bool R> struct is_ring<RingW<N, T, G, W, C, S, R>> { static constexpr bool value = true; };
 
 template <class WS>
 __device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }

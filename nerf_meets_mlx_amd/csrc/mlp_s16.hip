@@ -19,6 +19,13 @@
 #include "mlp_frag.h"
 #include "mlp_s16.h"
 
+// 1: the training forward re-reads its own stored encodings before pos5 / dir0 (48 registers less to carry through pos1..4; a
+// compiler-counted global load, i.e. a vmcnt(0) that drains the ring's DMAs and the pending stores); 0: keeps them (the 512-register
+// file of a one-wave-per-SIMD kernel has the room: they live in AGPRs)
+#ifndef NERF_S16_RELOAD_PE
+#define NERF_S16_RELOAD_PE 0
+#endif
+
 namespace nerf {
 namespace s16 {
 
@@ -30,8 +37,8 @@ static_assert(A_LO == L::A_MASK && A_MASK == 2 * L::A_MASK && A_SLOTS == A_MASK 
 static_assert(Z_LO == L::Z_SLOTS && Z_SLOTS == 2 * L::Z_SLOTS, "dZ slots");
 constexpr int NW = 4;                                    // waves per workgroup of the forward / chain kernels
 
-typedef RingW<F_CHUNKS, F_FRAGS, 4, NW> FwdRing;
-typedef RingW<B_CHUNKS, B_FRAGS, 4, NW> BwdRing;
+typedef RingW<F_CHUNKS, F_FRAGS, 4, NW, RING_CHUNK, RING_STAGES, true> FwdRing;      // DMA runs of four (mlp_ring.h)
+typedef RingW<B_CHUNKS, B_FRAGS, 4, NW> BwdRing;                                    // interleaved shares (RUN4 spills here)
 
 struct HL { bf16x2 h, l; };
 // two float32 values -> packed bf16 pair of their leading 8 bits, packed bf16 pair of the remainders
@@ -265,9 +272,13 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
   {                                                           // pos5 on concat[input_pos, h]  (models/NeRF.py:224-225)
     bf16x8 cth[20], ctl[20];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                             // register relief: the encoding was just stored
+    for (int k = 0; k < 4; ++k) {
+#if NERF_S16_RELOAD_PE                                        // register relief: the encoding was just stored
       cth[k] = *frag_ptr(a.acts, tile0, a.astride, L::A_PE + k, r, h);
       ctl[k] = *frag_ptr(a.acts, tile0, a.astride, A_LO + L::A_PE + k, r, h);
+#else
+      cth[k] = peh[k]; ctl[k] = pel[k];
+#endif
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) { cth[4 + k] = hah[k]; ctl[4 + k] = hal[k]; }
@@ -292,8 +303,12 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
     for (int k = 0; k < 16; ++k) { cth[k] = hah[k]; ctl[k] = hal[k]; }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
+#if NERF_S16_RELOAD_PE
       cth[16 + k] = *frag_ptr(a.acts, tile0, a.astride, L::A_DPE + k, r, h);
       ctl[16 + k] = *frag_ptr(a.acts, tile0, a.astride, A_LO + L::A_DPE + k, r, h);
+#else
+      cth[16 + k] = dph[k]; ctl[16 + k] = dpl[k];
+#endif
     }
     MASK_BEGIN();
     layer_fwd<18, 4, true, true>(ws, L::F_DIR, L::BI_DIR, cth, ctl, hdh, hdl, mk, lane, SINK(L::A_HD));
