@@ -43,7 +43,7 @@ def load_rows(paths):
                 continue
             r = json.loads(ln)
             if "seed" in r and "iter" in r and any(k.startswith("psnr_") for k in r):
-                rows[(r["seed"], r["iter"])] = r            # a re-run of a seed replaces the earlier rows
+                rows.setdefault((r["seed"], r["iter"]), {}).update(r)      # later files add arms to / replace values of a (seed, iter) row
     return rows
 
 

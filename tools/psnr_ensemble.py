@@ -127,6 +127,11 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
                               ref_quirks=quirks, precision=prec)
     arms = {"bf16": mk(getattr(a, "lead_precision", 16)), "fp32": mk(32)}        # key "bf16" = the lead arm (renamed on output when it is not 16)
     assert torch.equal(arms["bf16"].coarse.params, arms["fp32"].coarse.params)
+    if getattr(a, "lead_only", False):
+        # only the lead arm: its batches, uniforms, initial weights and evaluation pixels are functions of (seed, iteration), so the
+        # rows pair with the fp32 / bf16 arms of an EARLIER run of the same configuration and seeds (tools/psnr_converged_stats.py
+        # merges rows by (seed, iter))
+        del arms["fp32"]
     if getattr(a, "null_arm", False):
         # NULL arm: the SAME bf16 arithmetic, only the fp32 summation ORDER of the weight-gradient reduction differs (the
         # dW kernel's split-K count, an A/B knob: 240 workgroups instead of one per CU) -- relative differences of 1e-7 per
@@ -198,9 +203,10 @@ def run_seed(seed, a, dev="cuda", bridge=False, emit=print):
             if it % a.dead_every == 0 or it == iters:
                 dead["oracle"].update(it, lo, target, quirks)
         if it % a.every == 0 or it == iters:
-            rec = {"seed": seed, "iter": it, "psnr_bf16": psnr_of(arms["bf16"]), "psnr_fp32": psnr_of(arms["fp32"]),
-                   "elapsed_s": round(time.time() - t0, 1)}
-            rec["delta_db"] = rec["psnr_bf16"] - rec["psnr_fp32"]
+            rec = {"seed": seed, "iter": it, "psnr_bf16": psnr_of(arms["bf16"]), "elapsed_s": round(time.time() - t0, 1)}
+            if "fp32" in arms:
+                rec["psnr_fp32"] = psnr_of(arms["fp32"])
+                rec["delta_db"] = rec["psnr_bf16"] - rec["psnr_fp32"]
             if "bf16b" in arms:
                 rec["psnr_bf16b"] = psnr_of(arms["bf16b"])
                 rec["delta_db_null"] = rec["psnr_bf16b"] - rec["psnr_bf16"]
@@ -266,6 +272,7 @@ def main():
                     "checkpoint's delta is then the drift of ONE interval from a common state (short-horizon bias estimator)")
     ap.add_argument("--eval-pixels", type=int, default=0, help="evaluate the held-out PSNR on this many fixed pixels per test view (0: all)")
     ap.add_argument("--out", default="", help="also append every line to this file")
+    ap.add_argument("--lead-only", action="store_true", help="train the lead arm only (pairs with the arms of an earlier run of the same seeds)")
     ap.add_argument("--lead-precision", type=int, default=16, choices=[16, 22], help="precision of the lead arm (and of the null arm): 16 = "
                     "bf16 operands; 22 = the float32-tolerance mode on the 16-bit matrix pipe (split-bf16 training, split-fp16 rendering); "
                     "with 22 every 'bf16' in the output keys reads 'p22'")
@@ -300,6 +307,8 @@ def main():
         if a.null_arm:
             for st in summarise(recs, "psnr_bf16b", "psnr_bf16", "null_bf16b_minus_bf16"):
                 emit(json.dumps(st))
+        if a.lead_only:
+            return
         dead_any = lambda d: any(d[arm][net]["dead_at_end"] for arm in ("bf16", "fp32") for net in ("coarse", "fine"))
         alive = {sd for sd, d in deads.items() if not dead_any(d)}
         for st in summarise(recs, label="bf16_minus_fp32_alive_at_end_in_both_arms", only_seeds=alive):
