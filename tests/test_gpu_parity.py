@@ -616,16 +616,18 @@ def test_small_model_forward_backward_and_input_grads():
     assert torch.equal(m.backward(g.to(DEV)).cpu(), grads) or _rel_l2(m.grads.cpu(), grads) < 1e-5
 
 
-def test_ngp_field_gradients_and_training_track_oracle():
+@pytest.mark.parametrize("half_tables", [False, True])
+def test_ngp_field_gradients_and_training_track_oracle(half_tables):
     """configs[4]: hash grid (small tables so that autograd on the oracle is cheap) + SH + 2 x 64 MLP.  One batch:
     loss, MLP gradient and table gradient vs autograd through the bf16-emulating oracle; then 6 Adam iterations on
-    identical batches: losses track and fall."""
+    identical batches: losses track and fall.  half_tables (round 4, the default): the fused query gathers from the fp16 shadow
+    image of the tables -- same bars against the oracle; the fused == unfused BIT equality holds for float32 gathers only."""
     from nerf_meets_mlx_amd.engine.ngp import NGPTrainer
     from nerf_meets_mlx_amd.dataset import synthetic
     H = W = 32
     imgs, poses, _, hwf, K = synthetic.make_dataset(H, W, 2, seed=0, device=DEV)
     kw = dict(n_levels=16, min_res=4, max_res=128, n_features_per_level=2, log2_hashmap_size=12, hash_init_scale=0.5)
-    tr = NGPTrainer(imgs, poses, K, N_rand=256, n_depth_samples=32, seed=0, device=DEV, **kw)
+    tr = NGPTrainer(imgs, poses, K, N_rand=256, n_depth_samples=32, seed=0, device=DEV, half_tables=half_tables, **kw)
     orc = O.OracleNGP(tr.field.enc.tables.cpu(), tr.field.enc.scaled_res, seed=0, n_samples=32, emulate_bf16=True)
     assert torch.equal(tr.field.mlp.params.cpu(), orc.p.detach())
     rays, target = tr.sample_batch()
@@ -643,8 +645,12 @@ def test_ngp_field_gradients_and_training_track_oracle():
     gm_f, _ = tr.field.backward(g0); gm_f, gt_f = gm_f.clone(), tr.field.table_grad().clone()
     raw_u = tr.field.query(rays, z0, train=True, fused=False)
     gm_u, _ = tr.field.backward(g0); gt_u = tr.field.table_grad()
-    assert torch.equal(raw_f, raw_u)
-    assert _rel_l2(gm_f.cpu(), gm_u.cpu()) < 1e-5 and _rel_l2(gt_f.cpu(), gt_u.cpu()) < 1e-5    # atomics: order only
+    if half_tables:      # fp16 table values (2^-11) under the bf16 rounding of the interpolated features (2^-9)
+        assert float((raw_f - raw_u).abs().max()) < 5e-3 * float(raw_u.abs().max())
+        assert _rel_l2(gm_f.cpu(), gm_u.cpu()) < 2e-2 and _rel_l2(gt_f.cpu(), gt_u.cpu()) < 2e-2
+    else:
+        assert torch.equal(raw_f, raw_u)
+        assert _rel_l2(gm_f.cpu(), gm_u.cpu()) < 1e-5 and _rel_l2(gt_f.cpu(), gt_u.cpu()) < 1e-5    # atomics: order only
     # --- gradients of one batch (no update)
     from nerf_meets_mlx_amd.rendering import render
     from nerf_meets_mlx_amd.ops.metric import mse_loss_grad
