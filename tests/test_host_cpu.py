@@ -251,3 +251,23 @@ def test_pixel_permutation_is_a_uniform_sampler():
         assert first < bound(31) and rc < bound(63), (name, first, rc)
         assert abs(corr) < 5.0 / np.sqrt(S * (n - 1)) * 1.2, (name, corr)
         assert 1.3 < overlap < 2.0, (name, overlap)
+
+
+def test_c_abi_header_compiles_as_c_and_library_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/nerf_hip.h compiled by gcc as C (-std=c99 -Wall -Werror), linked against the in-tree
+    libnerf_hip.so, host-only entry points called from C (tests/abi/abi_check.c) -- no Python, no GPU."""
+    import shutil
+    import subprocess
+    import __graft_entry__ as g
+    from nerf_meets_mlx_amd import _native
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    if not os.path.exists(_native.LIB_PATH):
+        g.build()
+    libdir = os.path.dirname(os.path.abspath(_native.LIB_PATH))
+    exe = str(tmp_path / "abi_check")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi", "abi_check.c"),
+                    "-L", libdir, "-lnerf_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_check ok" in out.stdout
