@@ -282,10 +282,16 @@ __device__ __forceinline__ void tiles22(const FwdArgs& a, WS& ws, int64_t wtile0
       } else {
         const int64_t ray = (int64_t)((unsigned)m / (unsigned)a.n);            // M < 2^31 (checked on the host)
         const float* rr = a.rays + ray * NERF_RAY_STRIDE;
-        const float zv = a.z[m];
         float p[3], d[3];
+#if NERF_ABLATE == 3          // timing-only build 3: no input loads at the head of a pass (positions from the lane id)
+        (void)rr;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p[k] = 0.001f * (float)(m & 1023) + (float)k; d[k] = 0.5f; }
+#else
+        const float zv = a.z[m];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { p[k] = rr[k] + zv * rr[3 + k]; d[k] = rr[8 + k]; }   // render.py:142
+#endif
         pe22_encode(q, p, d, peh[s], pel[s], dph[s], dpl[s]);
       }
     }
