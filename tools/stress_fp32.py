@@ -6,6 +6,7 @@ counted s_waitcnt: a wait that passes too early shows up here as a handful of di
 first version of the store-aware waits did), long before an accuracy test notices.
 
     python tools/stress_fp32.py 400        # 0 mismatches on the round's final kernels
+    python tools/stress_fp32.py 400 22     # the same for the split-precision kernels (round 4)
 """
 import sys
 
@@ -23,11 +24,13 @@ def rays(B, dev):
     return r
 
 
-def run(iters=200, B=4096, n=192, dev="cuda", verbose=True):
-    """Returns the number of (iteration, tensor) pairs that differed from the first iteration."""
+def run(iters=200, B=4096, n=192, dev="cuda", verbose=True, precision=32):
+    """Returns the number of (iteration, tensor) pairs that differed from the first iteration.  precision 22: the split
+    kernels (csrc/mlp22.hip, csrc/mlp_s16.hip: LDS ring with M0-clobbering DMA runs, half-tile pair-block staging in dW);
+    their training and inference forwards are different kernels, so those two are not compared with each other."""
     from nerf_meets_mlx_amd.models.NeRF import NeRF
     torch.manual_seed(0)
-    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0, precision=32)
+    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0, precision=precision)
     m16 = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=1, precision=16)
     r = rays(B, dev)
     z = torch.sort(torch.rand(B, n, device=dev) * 4 + 2, -1).values
@@ -46,7 +49,7 @@ def run(iters=200, B=4096, n=192, dev="cuda", verbose=True):
         cur = (raw, gr, inf)
         if ref is None:
             ref = cur
-            assert torch.equal(raw, inf), "training and inference forward differ"
+            assert precision != 32 or torch.equal(raw, inf), "training and inference forward differ"
             continue
         for a, b, name in zip(ref, cur, ("raw_train", "grads", "raw_inference")):
             if not torch.equal(a, b):
@@ -59,6 +62,6 @@ def run(iters=200, B=4096, n=192, dev="cuda", verbose=True):
 
 
 if __name__ == "__main__":
-    n_bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200)
+    n_bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, precision=int(sys.argv[2]) if len(sys.argv) > 2 else 32)
     print("done bad =", n_bad)
     sys.exit(1 if n_bad else 0)
