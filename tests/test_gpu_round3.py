@@ -426,7 +426,7 @@ def test_psnr_paired_ensemble_bf16_vs_reference_arithmetic():
     checkpoint the mean paired difference is zero within its own 95 % confidence interval widened by those 0.1 dB -- a
     systematic bf16 deficit or gain of a few tenths of a dB fails; (c) the number of seeds that END in the dead-sigma
     state differs by at most one between the arms (the unconditional part: survival itself is compared).  The converged
-    regime (16 seeds x 20 000 iterations at 800 x 800) is profiles/r04_psnr_converged_*.jsonl, DESIGN.md 5.3."""
+    regime (24 seeds x 20 000 iterations at 800 x 800) is profiles/r04_psnr_converged_*.jsonl, DESIGN.md 5.3."""
     import argparse
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

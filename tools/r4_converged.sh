@@ -1,7 +1,8 @@
 #!/bin/bash
 # One gpurun call of the round-4 converged-regime PSNR ensemble: 800 x 800, N_rand 1024, 20 000 iterations,
 # held-out PSNR every 1000 on 80 000 fixed pixels of 2 test views; arms bf16 / fp32 (reference arithmetic) / bf16b (null arm).
-# Seeds = the first 16 alive-at-init seeds from 0, fixed BEFORE any run: 4 10 18 21 | 28 33 47 58 | 64 69 71 81 | 88 101 103 123
+# Seeds = the first 24 alive-at-init seeds from 0, fixed BEFORE any run: 4 10 18 21 | 28 33 47 58 | 64 69 71 81 | 88 101 103 123 |
+# 127 138 143 169 | 178 185 196 200
 #   tools/r4_converged.sh A 4,10,18,21
 set -e
 TAG=$1; SEEDS=$2

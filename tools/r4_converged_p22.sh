@@ -1,7 +1,7 @@
 #!/bin/bash
 # Precision-22 arm of the converged-regime ensemble (same configuration and seeds as tools/r4_converged.sh; lead arm only: its
 # batches, uniforms, initial weights and evaluation pixels are functions of (seed, iteration), so the rows pair with the stored
-# bf16 / fp32 / null arms of profiles/r04_psnr_converged_16seeds_*.jsonl).
+# bf16 / fp32 / null arms of profiles/r04_psnr_converged_24seeds_*.jsonl).
 #   tools/r4_converged_p22.sh A 4,10,18,21,28,33,47,58
 set -e
 TAG=$1; SEEDS=$2
