@@ -31,13 +31,17 @@ def latest_checkpoint(ckpt_dir: str) -> Optional[str]:
 
 def main(path_dataset: Optional[str] = None, max_iter: int = 5000, device="cuda", ref_quirks: bool = True,
          hw_synthetic: int = 800, n_train_synthetic: int = 100, render_every: int = 50000, n_render_poses: int = 0,
-         log_every: int = 100, seed: int = 4, argv=None):
+         log_every: int = 100, seed: int = 4, argv=None, precision: Optional[int] = None):
     """argv: extra command-line flags of `config_parser` (e.g. ["--basedir", d, "--expname", "lego", "--i_weights",
     "1000", "--ft_path", f, "--no_reload"]).  Checkpoint flags (config_parser.py:25-26,75; declared upstream, with
     `models/NeRF.py:122-125` left as TODOs): every `--i_weights` iterations the trainer state goes to
     `{basedir}/{expname}/{it:06d}.npz`; at start `--ft_path` (if given) or, unless `--no_reload`, the newest
     checkpoint of that directory is loaded and training continues from its iteration.  In quirk mode a config file
-    forces no_reload like upstream does (config_parser.py:120)."""
+    forces no_reload like upstream does (config_parser.py:120).
+    precision (ours; default from NERF_PRECISION, else 22): 22 = the reference's float32 tolerance on the 16-bit matrix pipe
+    (what bench.py measures), 32 = float32 operands on the fp32 MFMA, 16 = bf16 operands (declared reduced precision)."""
+    if precision is None:
+        precision = int(os.environ.get("NERF_PRECISION", "22"))
     args = config_parser.config_parser().parse_args(args=list(argv or []))
     if path_dataset is not None:
         configs = config_parser.load_config(None, os.path.join(path_dataset, "configs/lego.txt"))
@@ -58,7 +62,8 @@ def main(path_dataset: Optional[str] = None, max_iter: int = 5000, device="cuda"
         near, far = 2.0, 6.0
     tr = Trainer(train_imgs, train_poses, K, near=near, far=far, N_rand=args.N_rand, n_depth_samples=args.n_depth_samples,
                  N_importance=args.N_importance, lrate=args.lrate, lrate_decay=args.lrate_decay,
-                 white_bkgd=bool(args.white_bkgd), ref_quirks=ref_quirks, seed=seed, device=device, chunk=args.chunk)
+                 white_bkgd=bool(args.white_bkgd), ref_quirks=ref_quirks, seed=seed, device=device, chunk=args.chunk,
+                 precision=precision)
     ckpt_dir = checkpoint_dir(args)
     resume = args.ft_path if args.ft_path else (None if args.no_reload else latest_checkpoint(ckpt_dir))
     if resume is not None:
