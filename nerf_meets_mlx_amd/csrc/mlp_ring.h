@@ -71,14 +71,6 @@ __device__ __forceinline__ void dma_frag_nt(const void* gsrc_lane, unsigned lds_
                : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_addr) : "memory");
 #endif
 }
-#if NERF_DMA_CLOBBER_M0
-// follow-up DMA of a run of consecutive fragments: M0 and the source base are the ones the run's first dma_frag_s left behind;
-// the instruction's immediate offset moves BOTH the global and the LDS address (1 KiB per fragment; 13-bit signed: up to 3 KiB)
-template <int OFF>
-__device__ __forceinline__ void dma_frag_next(const void* gbase_uniform, unsigned lane_off) {
-  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" :: "v"(lane_off), "s"(gbase_uniform), "n"(OFF) : "memory");
-}
-#endif
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
@@ -107,9 +99,8 @@ extern __shared__ __attribute__((aligned(16))) char ring_smem[];
 // consumed per pass (multiple of RING_GROUP)
 // CHUNK / STAGES: fragments per ring stage and stages (default 32 x 4 = 128 KiB for one 8-wave workgroup per CU; 16 x 4 =
 // 64 KiB lets two independent 4-wave workgroups share a CU, see mlp_fwd_ring_kernel)
-// RUN4 (needs NERF_DMA_CLOBBER_M0 and 8 DMAs per wave and chunk): see issue_one.  Opt-in per kernel: it pays in the two forward
-// kernels of the split-precision modes (-3 % on the split-fp16 forward); in the split-bf16 chain kernel it tipped hipcc's
-// register allocation into scratch (+3 ms), so that one keeps the interleaved shares.
+// RUN4 (needs NERF_DMA_CLOBBER_M0 and 8 DMAs per wave and chunk): see issue_one.  Opt-in per kernel (the 4-wave rings of the
+// split-precision kernels).
 template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES, bool RUN4 = false>
 struct RingW {
   static constexpr int DPW = CHUNK / NW;               // DMAs per wave per chunk
@@ -125,21 +116,22 @@ struct RingW {
 
   // this wave's k-th (of DPW) share of `chunk`: fragments wv + NW k -- or, with M0-clobbering DMA statements and 8 DMAs per
   // wave and chunk (the 4-wave rings of the split-precision kernels), the CONSECUTIVE fragments DPW wv + k: a run of four then
-  // shares one M0 write, one hazard nop and one source base, the other three are a bare DMA with an immediate offset (the DMAs of a
-  // chunk are issued in order k = 0..7 and nothing else writes M0 in these kernels: tools/check_m0.py)
+  // shares one M0 write, one hazard nop and one source base, the other three are a bare DMA with an immediate offset, which moves
+  // BOTH the global and the LDS address (1 KiB per fragment; 13-bit signed: up to 3 KiB).  The DMAs of a chunk are issued in order
+  // k = 0..7 and nothing else writes M0 in these kernels (tools/check_m0.py)
   const char* run_base;                // source base of the current run of four (NERF_DMA_CLOBBER_M0, DPW == 8)
   __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
 #if NERF_DMA_CLOBBER_M0
     if (RUN4 && DPW == 8) {
       const int i = wv * DPW + k;
-      switch (k & 3) {
-        case 0:
-          run_base = wsrc + ((int64_t)chunk * CHUNK + i) * 1024;
-          dma_frag_s(run_base, lane16, lds0 + stage * STAGE_BYTES + i * 1024);
-          break;
-        case 1: dma_frag_next<1024>(run_base, lane16); break;
-        case 2: dma_frag_next<2048>(run_base, lane16); break;
-        default: dma_frag_next<3072>(run_base, lane16); break;
+      if ((k & 3) == 0) {
+        run_base = wsrc + ((int64_t)chunk * CHUNK + i) * 1024;
+        dma_frag_s(run_base, lane16, lds0 + stage * STAGE_BYTES + i * 1024);
+      } else {
+        // ONE asm template with an immediate operand (k is a constant at every call site after unrolling).  A switch over three
+        // templated statements compiled to the same DMAs but tipped hipcc's register allocation of the split-bf16 chain kernel
+        // into scratch (857 scratch instructions, +3 ms, all tests green): the Makefile scan now fails the build on that.
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" :: "v"(lane16), "s"(run_base), "i"((k & 3) * 1024) : "memory");
       }
       return;
     }

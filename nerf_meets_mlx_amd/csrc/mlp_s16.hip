@@ -38,7 +38,7 @@ static_assert(Z_LO == L::Z_SLOTS && Z_SLOTS == 2 * L::Z_SLOTS, "dZ slots");
 constexpr int NW = 4;                                    // waves per workgroup of the forward / chain kernels
 
 typedef RingW<F_CHUNKS, F_FRAGS, 4, NW, RING_CHUNK, RING_STAGES, true> FwdRing;      // DMA runs of four (mlp_ring.h)
-typedef RingW<B_CHUNKS, B_FRAGS, 4, NW> BwdRing;                                    // interleaved shares (RUN4 spills here)
+typedef RingW<B_CHUNKS, B_FRAGS, 4, NW, RING_CHUNK, RING_STAGES, true> BwdRing;
 
 struct HL { bf16x2 h, l; };
 // two float32 values -> packed bf16 pair of their leading 8 bits, packed bf16 pair of the remainders
