@@ -564,7 +564,12 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
         const int nfr = is_z ? jb.nf : jb.kf;
         int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;        // odd counts (rgb / alpha: nf = 1): rows past n_valid, never read back
         const int slot = (is_z ? jb.dz_slot + lo_part * Z_LO : jb.act_slot + lo_part * A_LO) + fr;
+#if NERF_ABLATE == 9          // timing-only build 9: every DMA reads ONE contiguous KiB (wrong operands): what the two 512-byte halves cost
+        const char* src = (is_z ? dzb + tile * a.zstride * 16 : acb + tile * a.astride * 16) + (int64_t)(slot - src_sel + (ht & 1)) * 1024 + 16 * lane;
+        (void)row_off;
+#else
         const char* src = (is_z ? dzb + tile * a.zstride * 16 : acb + tile * a.astride * 16) + (int64_t)slot * 1024 + row_off;
+#endif
         dma_frag_nt(src, st + i * 1024);
       } else {
         dma_frag(dzb + tile * a.zstride * 16 + (int64_t)jb.dz_slot * 1024 + 16 * lane, sink);   // padding: L2 hit, result unused
