@@ -25,11 +25,13 @@
 #include "mlp_ring.h"
 #include "mlp_layout.h"
 #include "mlp_frag.h"
+#include "mlp_arch2.h"
 #include "hash_common.h"
 #include "mlp_params.h"
 #include "mlp32.h"
 #include "mlp22.h"
 #include "mlp_s16.h"
+#include "mlp_s16x.h"
 #include <string.h>
 #include <mutex>
 #include <unordered_map>
@@ -1085,56 +1087,6 @@ __global__ void __launch_bounds__(256) mlp_dw_reduce_kernel(DwArgs a) {
 // is_use_view_directions=False)): pos0 [256x40] pos1..4 [256x256] pos5 [256x296] pos6 pos7 output [out_ch x 256]
 // (models/NeRF.py:182-197,241).  Same register-resident transposed scheme, same ring, same dW kernel.
 // ==========================================================================================
-namespace LI {
-constexpr int CIN = 40;
-constexpr int P_W0 = 0, P_B0 = 10240, P_W1 = 10496, P_W5 = 273664, P_B5 = 349440;
-constexpr int P_W6 = 349696, P_B6 = 415232, P_W7 = 415488, P_B7 = 481024, P_WO = 481280;
-__host__ __device__ constexpr int pw(int l) {
-  return l == 0 ? P_W0 : l <= 4 ? P_W1 + (l - 1) * 65792 : l == 5 ? P_W5 : l == 6 ? P_W6 : P_W7;
-}
-__host__ __device__ constexpr int pb(int l) {
-  return l == 0 ? P_B0 : l <= 4 ? P_W1 + (l - 1) * 65792 + 65536 : l == 5 ? P_B5 : l == 6 ? P_B6 : P_B7;
-}
-constexpr int F_L0 = 0, F_L1 = 24, F_L5 = 536, F_L6 = 688, F_L7 = 816, F_OUT = 944, F_TOTAL = 960;
-constexpr int B_OUT = 0, B_L7 = 8, B_TOTAL = 904, B_PADDED = 928;       // OUT^T, pos7..pos1 (pos5: H4 columns)
-constexpr int BI_OUT = 2048, BI_TOTAL = 2080;
-constexpr int A_X = 0, A_H0 = 3, A_MASK = 131, A_SLOTS = 139;
-constexpr int Z_L0 = 0, Z_OUT = 128, Z_SLOTS = 129;
-constexpr int F_CHUNKS = F_TOTAL / RING_CHUNK, B_CHUNKS = B_PADDED / RING_CHUNK;   // 30, 29
-static_assert(F_CHUNKS * RING_CHUNK == F_TOTAL && B_CHUNKS * RING_CHUNK == B_PADDED, "whole chunks");
-}  // namespace LI
-
-__device__ float fwd_src_img(const float* __restrict__ p, int f, int r, int h, int j, int out_ch) {
-  if (f < LI::F_L1) {                                  // pos0: K space 48 (40 + pad)
-    const int nt = f / 3, ks = f % 3, kk = kperm(ks, h, j);
-    return kk < 40 ? p[LI::P_W0 + (32 * nt + r) * 40 + kk] : 0.0f;
-  }
-  if (f < LI::F_L5) {
-    const int l = 1 + (f - LI::F_L1) / 128, g = (f - LI::F_L1) % 128;
-    return p[LI::pw(l) + (32 * (g / 16) + r) * 256 + kperm(g % 16, h, j)];
-  }
-  if (f < LI::F_L6) {                                  // pos5: [x(48), H4(256)] vs W5[256][296]
-    const int g = f - LI::F_L5, nt = g / 19, ks = g % 19, kk = kperm(ks, h, j), n = 32 * nt + r;
-    if (kk < 48) return kk < 40 ? p[LI::P_W5 + n * 296 + kk] : 0.0f;
-    return p[LI::P_W5 + n * 296 + 40 + (kk - 48)];
-  }
-  if (f < LI::F_OUT) {
-    const int l = 6 + (f - LI::F_L6) / 128, g = (f - LI::F_L6) % 128;
-    return p[LI::pw(l) + (32 * (g / 16) + r) * 256 + kperm(g % 16, h, j)];
-  }
-  return r < out_ch ? p[LI::P_WO + r * 256 + kperm(f - LI::F_OUT, h, j)] : 0.0f;
-}
-
-__device__ float bwd_src_img(const float* __restrict__ p, int f, int r, int h, int j, int out_ch) {
-  if (f < LI::B_L7) {                                  // output^T: 8 tiles of H7, one k-step (rows 0..out_ch-1)
-    const int nn = kperm(0, h, j);
-    return nn < out_ch ? p[LI::P_WO + nn * 256 + 32 * f + r] : 0.0f;
-  }
-  const int g = f - LI::B_L7, li = g / 128, q = g % 128, kt = q / 16, ns = q % 16;
-  const int l = 7 - li, nn = kperm(ns, h, j), row = 32 * kt + r;
-  if (l == 5) return p[LI::P_W5 + nn * 296 + 40 + row];
-  return p[LI::pw(l) + nn * 256 + row];
-}
 
 __global__ void __launch_bounds__(256) pack_img_kernel(const float* __restrict__ p, bf16x8* __restrict__ wf,
                                                        bf16x8* __restrict__ wb, float* __restrict__ bias, int out_ch) {
@@ -1302,44 +1254,6 @@ __global__ void __launch_bounds__(512, 2) mlp_img_bwd_ring_kernel(ImgArgs a) {
 // its 8 waves then run independently over sample tiles.  Same register-resident chain, same fragment-block stores,
 // same dW kernel (7 jobs); the chain additionally returns dL/d(input features) for the hash-grid backward.
 // ==========================================================================================
-namespace LN {
-constexpr int CPOS = 32, CDIR = 16, CIN = CPOS + CDIR;
-constexpr int P_W0 = 0, P_B0 = 2048, P_W1 = 2112, P_B1 = 6208, P_WF = 6272, P_BF = 10368, P_WA = 10432, P_BA = 10496;
-constexpr int P_WD = 10497, P_BD = 13057, P_WR = 13089, P_BR = 13185, P_TOTAL = 13188;
-constexpr int F_L0 = 0, F_L1 = 4, F_FA = 12, F_DIR = 24, F_RGB = 29, F_TOTAL = 31, F_PADDED = 32;
-constexpr int B_RGB = 0, B_DIR = 1, B_FA = 5, B_L1 = 15, B_L0 = 23, B_TOTAL = 27, B_PADDED = 32;
-constexpr int BI_L0 = 0, BI_L1 = 64, BI_FEAT = 128, BI_ALPHA = 192, BI_DIR = 224, BI_RGB = 256, BI_TOTAL = 288;
-constexpr int64_t PACKED_BYTES = (int64_t)(F_PADDED + B_PADDED) * 1024 + BI_TOTAL * 4;
-constexpr int A_X = 0, A_DX = 2, A_H0 = 3, A_H1 = 7, A_FEAT = 11, A_HD = 15, A_MASK = 17, A_SLOTS = 20;
-constexpr int Z_L0 = 0, Z_L1 = 4, Z_F = 8, Z_A = 12, Z_D = 13, Z_RGB = 15, Z_SLOTS = 16;
-constexpr int LDS_BYTES = 32 * 1024 + BI_TOTAL * 4;
-}  // namespace LN
-
-__device__ float fwd_src_small(const float* __restrict__ p, int f, int r, int h, int j) {
-  if (f < LN::F_L1) { const int nt = f / 2, ks = f % 2; return p[LN::P_W0 + (32 * nt + r) * 32 + kperm(ks, h, j)]; }
-  if (f < LN::F_FA) { const int g = f - LN::F_L1, nt = g / 4, ks = g % 4; return p[LN::P_W1 + (32 * nt + r) * 64 + kperm(ks, h, j)]; }
-  if (f < LN::F_DIR) {
-    const int g = f - LN::F_FA;
-    if (g < 8) return p[LN::P_WF + (32 * (g / 4) + r) * 64 + kperm(g % 4, h, j)];
-    return r == 0 ? p[LN::P_WA + kperm(g - 8, h, j)] : 0.0f;
-  }
-  if (f < LN::F_RGB) { const int ks = f - LN::F_DIR; return p[LN::P_WD + r * 80 + kperm(ks, h, j)]; }      // [feature(64), sh(16)]
-  if (f < LN::F_TOTAL) return r < 3 ? p[LN::P_WR + r * 32 + kperm(f - LN::F_RGB, h, j)] : 0.0f;
-  return 0.0f;
-}
-// transposed stream: A rows = INPUT feature (32 kt + r), k index = OUTPUT feature nn
-__device__ float bwd_src_small(const float* __restrict__ p, int f, int r, int h, int j) {
-  if (f < LN::B_DIR) { const int nn = kperm(0, h, j); return nn < 3 ? p[LN::P_WR + nn * 32 + r] : 0.0f; }
-  if (f < LN::B_FA) { const int g = f - LN::B_DIR, kt = g / 2, ns = g % 2; return p[LN::P_WD + kperm(ns, h, j) * 80 + 32 * kt + r]; }
-  if (f < LN::B_L1) {
-    const int g = f - LN::B_FA, kt = g / 5, ns = g % 5, nn = kperm(ns, h, j);
-    if (ns < 4) return p[LN::P_WF + nn * 64 + 32 * kt + r];
-    return nn == 64 ? p[LN::P_WA + 32 * kt + r] : 0.0f;
-  }
-  if (f < LN::B_L0) { const int g = f - LN::B_L1, kt = g / 4, ns = g % 4; return p[LN::P_W1 + kperm(ns, h, j) * 64 + 32 * kt + r]; }
-  if (f < LN::B_TOTAL) return p[LN::P_W0 + kperm(f - LN::B_L0, h, j) * 32 + r];
-  return 0.0f;
-}
 __global__ void __launch_bounds__(256) pack_small_kernel(const float* __restrict__ p, bf16x8* __restrict__ wf,
                                                          bf16x8* __restrict__ wb, float* __restrict__ bias) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -1612,7 +1526,7 @@ static void ensure_lds(K kernel, int bytes) {
 static int arch_kind(const nerf_mlp_arch* a) {
   if (!a) return -1;
   if (a->precision != 0 && a->precision != 16 && a->precision != 32 && a->precision != 22) return -1;
-  if ((arch_f32(a) || arch_s16(a)) && !(a->n_layers == 8 && a->width == 256 && a->use_viewdirs == 1)) return -1;   // fp32 / split-fp16 kernels: 8 x 256 view model only
+  if (arch_f32(a) && !(a->n_layers == 8 && a->width == 256)) return -1;   // fp32 MFMA kernels: the 8 x 256 models (view head or image)
   if (a->n_layers == 2 && a->width == 64 && a->skip_layer < 0 && a->use_viewdirs == 1 && a->in_pos == 32 && a->in_dir == 16) return 2;
   if (a->n_layers != 8 || a->width != 256 || a->skip_layer != 4) return -1;
   if (a->use_viewdirs == 1 && a->in_pos == 63 && a->in_dir == 27) return 0;
@@ -1620,11 +1534,20 @@ static int arch_kind(const nerf_mlp_arch* a) {
   return -1;
 }
 static bool arch_ok(const nerf_mlp_arch* a) { return arch_kind(a) == 0; }
-static inline int64_t img_astride16() { return (int64_t)LI::A_SLOTS * 64 + g_tile_pad16; }
-static inline int64_t img_zstride16() { return (int64_t)LI::Z_SLOTS * 64 + g_tile_pad16; }
+static inline int64_t img_astride16(bool split = false) { return (int64_t)(split ? s16x::IMG_A_SLOTS : LI::A_SLOTS) * 64 + g_tile_pad16; }
+static inline int64_t img_zstride16(bool split = false) { return (int64_t)(split ? s16x::IMG_Z_SLOTS : LI::Z_SLOTS) * 64 + g_tile_pad16; }
 static inline int64_t img_params(const nerf_mlp_arch* a) { return LI::P_WO + (int64_t)a->out_ch * 257; }
-static inline int64_t small_astride16() { return (int64_t)LN::A_SLOTS * 64 + g_tile_pad16; }
-static inline int64_t small_zstride16() { return (int64_t)LN::Z_SLOTS * 64 + g_tile_pad16; }
+static inline int64_t small_astride16(bool split = false) { return (int64_t)(split ? s16x::SM_A_SLOTS : LN::A_SLOTS) * 64 + g_tile_pad16; }
+static inline int64_t small_zstride16(bool split = false) { return (int64_t)(split ? s16x::SM_Z_SLOTS : LN::Z_SLOTS) * 64 + g_tile_pad16; }
+// bf16 images of the image-fitting / 2 x 64 models (a precision-22 model carries its split-bf16 pair streams behind them and
+// shares their fp32 bias slots)
+constexpr int64_t IMG_BF16_BYTES = (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4;
+static inline const float* img_bias_of(const void* packed) {
+  return reinterpret_cast<const float*>(static_cast<const char*>(packed) + (size_t)(LI::F_TOTAL + LI::B_PADDED) * 1024);
+}
+static inline const float* small_bias_of(const void* packed) {
+  return reinterpret_cast<const float*>(static_cast<const char*>(packed) + (size_t)(LN::F_PADDED + LN::B_PADDED) * 1024);
+}
 
 }  // namespace nerf
 
@@ -1670,7 +1593,9 @@ extern "C" int64_t nerf_mlp_packed_bytes(const nerf_mlp_arch* arch) {
   const int k = arch_kind(arch);
   // an fp32 (precision 32) 8 x 256 view model carries its fp32 streams behind the bf16 image
   // ... and a precision-22 model its split-fp16 stream behind that
-  return k == 0 ? L::PACKED_BYTES + (arch_f32(arch) ? f32::PACKED_BYTES : 0) + (arch_s16(arch) ? f22::PACKED_BYTES + s16::PACKED_BYTES : 0) : k == 1 ? (int64_t)(LI::F_TOTAL + LI::B_PADDED) * 1024 + LI::BI_TOTAL * 4 : k == 2 ? LN::PACKED_BYTES : -1;
+  return k == 0 ? L::PACKED_BYTES + (arch_f32(arch) ? f32::PACKED_BYTES : 0) + (arch_s16(arch) ? f22::PACKED_BYTES + s16::PACKED_BYTES : 0)
+         : k == 1 ? IMG_BF16_BYTES + (arch_s16(arch) ? s16x::IMG_PACKED_BYTES : 0) + (arch_f32(arch) ? f32::PACKED_BYTES : 0)
+         : k == 2 ? LN::PACKED_BYTES + (arch_s16(arch) ? s16x::SM_PACKED_BYTES : 0) : -1;
 }
 static inline const void* packed32_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES; }
 static inline const void* packed22_of(const void* packed) { return static_cast<const char*>(packed) + L::PACKED_BYTES; }
@@ -1684,17 +1609,19 @@ static inline int64_t padded_tiles(int64_t M) { return (((M + 31) / 32) + 7) / 8
 extern "C" int64_t nerf_mlp_acts_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
-  const int64_t b16 = padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16() : small_astride16()) * 16;
+  const bool sp = arch_s16(arch);
+  const int64_t b16 = padded_tiles(M) * (k == 0 ? astride16() : k == 1 ? img_astride16(sp) : small_astride16(sp)) * 16;
   if (k == 0 && arch_s16(arch)) return padded_tiles(M) * s16_astride16() * 16;
-  return (k == 0 && arch_f32(arch)) ? f32::acts_bytes(M) : b16;
+  return (k <= 1 && arch_f32(arch)) ? f32::acts_bytes(M) : b16;
 }
 extern "C" int64_t nerf_mlp_dz_bytes(const nerf_mlp_arch* arch, int64_t M) {
   const int k = arch_kind(arch);
   if (k < 0 || M < 0) return -1;
-  const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16() : small_zstride16()) * 16
+  const bool sp = arch_s16(arch);
+  const int64_t b16 = padded_tiles(M) * (k == 0 ? zstride16() : k == 1 ? img_zstride16(sp) : small_zstride16(sp)) * 16
                       + DW_PARTIAL_BYTES;                 // + the split-K partial tiles of the weight-gradient kernel
   if (k == 0 && arch_s16(arch)) return padded_tiles(M) * s16_zstride16() * 16 + DW_PARTIAL_BYTES;
-  return (k == 0 && arch_f32(arch)) ? f32::dz_bytes(M) : b16;
+  return (k <= 1 && arch_f32(arch)) ? f32::dz_bytes(M) : b16;
 }
 
 #define NERF_ARCH_MSG ": HIP kernels exist for (8x256, skip 4) with in=63+27 view head, or in=40 / no view head / out_ch<=4, and for (2x64, no skip) with in=32+16 view head"
@@ -1710,7 +1637,9 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
     hipLaunchKernelGGL(pack_small_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), params,
                        reinterpret_cast<bf16x8*>(base), reinterpret_cast<bf16x8*>(base + (size_t)LN::F_PADDED * 1024),
                        reinterpret_cast<float*>(base + (size_t)(LN::F_PADDED + LN::B_PADDED) * 1024));
-    return check_launch("nerf_mlp_pack (2x64 model)");
+    int rcn = check_launch("nerf_mlp_pack (2x64 model)");
+    if (!rcn && arch_s16(arch)) rcn = s16x::small_pack(params, base + LN::PACKED_BYTES, as_stream(stream));
+    return rcn;
   }
   if (arch_kind(arch) == 1) {
     bf16x8* wfi = reinterpret_cast<bf16x8*>(base);
@@ -1719,7 +1648,10 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
     const int tot = (LI::F_TOTAL + LI::B_PADDED) * 64 + LI::BI_TOTAL;
     hipLaunchKernelGGL(pack_img_kernel, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), params, wfi, wbi, bi,
                        arch->out_ch);
-    return check_launch("nerf_mlp_pack (image model)");
+    int rci = check_launch("nerf_mlp_pack (image model)");
+    if (!rci && arch_s16(arch)) rci = s16x::img_pack(params, arch->out_ch, base + IMG_BF16_BYTES, as_stream(stream));
+    if (!rci && arch_f32(arch)) rci = f32::pack(params, base + IMG_BF16_BYTES, arch->out_ch, as_stream(stream));
+    return rci;
   }
   bf16x8* wf = reinterpret_cast<bf16x8*>(base);
   bf16x8* wb = reinterpret_cast<bf16x8*>(base + (size_t)L::F_TOTAL * 1024);
@@ -1728,7 +1660,7 @@ extern "C" int nerf_mlp_pack(const nerf_mlp_arch* arch, const float* params, voi
                      reinterpret_cast<bf16x8*>(base + L::F16_OFFSET));
   int rc = check_launch("nerf_mlp_pack");
   if (rc) return rc;
-  if (arch_f32(arch)) rc = f32::pack(params, base + L::PACKED_BYTES, as_stream(stream));
+  if (arch_f32(arch)) rc = f32::pack(params, base + L::PACKED_BYTES, 0, as_stream(stream));
   if (!rc && arch_s16(arch)) rc = f22::pack(params, base + L::PACKED_BYTES, as_stream(stream));
   if (!rc && arch_s16(arch)) rc = s16::pack(params, base + L::PACKED_BYTES + f22::PACKED_BYTES, as_stream(stream));
   return rc;
@@ -1826,6 +1758,9 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
   if (arch_kind(arch) == 2) {
     SmallArgs a;
     small_args(a, packed);
+    if (arch_s16(arch))                        // split bf16: float32-class products (mlp_s16x.hip)
+      return s16x::small_forward(static_cast<const char*>(packed) + LN::PACKED_BYTES, small_bias_of(packed), x, M, out, acts,
+                                 small_astride16(true), nullptr, as_stream(stream));
     a.x = x; a.out = out; a.acts = acts; a.M = M;
     const int64_t nwg = ((M + 31) / 32 + 7) / 8;
     const dim3 g((unsigned)(nwg < 2048 ? nwg : 2048)), b(512);
@@ -1834,6 +1769,12 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     return check_launch("mlp forward (2x64 model)");
   }
   if (arch_kind(arch) == 1) {
+    if (arch_f32(arch))                        // float32 operands on the fp32 MFMA (mlp32.hip)
+      return f32::forward(static_cast<const char*>(packed) + IMG_BF16_BYTES, x, nullptr, nullptr, M, 1, 0, out, acts, arch->out_ch,
+                          as_stream(stream));
+    if (arch_s16(arch))
+      return s16x::img_forward(static_cast<const char*>(packed) + IMG_BF16_BYTES, img_bias_of(packed), x, M, arch->out_ch, out, acts,
+                               img_astride16(true), ring_wgs(), as_stream(stream));
     ImgArgs a;
     img_args(a, arch, packed);
     a.x = x; a.out = out; a.acts = acts; a.M = M;
@@ -1851,7 +1792,7 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     return s16::forward(packed_s16_of(packed), bias_slots_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, s16_astride16(),
                         ring_wgs(), as_stream(stream));
   if (arch_f32(arch)) {
-    return f32::forward(packed32_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, as_stream(stream));
+    return f32::forward(packed32_of(packed), x, nullptr, nullptr, M, 1, 0, out, acts, 0, as_stream(stream));
   }
   return launch_fwd<0>(packed, x, nullptr, nullptr, M, 1, 0, out, acts, stream);
 }
@@ -1875,14 +1816,14 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
     return s16::forward(packed_s16_of(packed), bias_slots_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts,
                         s16_astride16(), ring_wgs(), as_stream(stream));
   if (arch_f32(arch)) {
-    return f32::forward(packed32_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts, as_stream(stream));
+    return f32::forward(packed32_of(packed), nullptr, rays, z, B * n, n, freq_mode, raw, acts, 0, as_stream(stream));
   }
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
 }
 
 // split the (dZ, H) jobs over workgroups and launch the dW kernel; grads[0..nparams) is overwritten
 static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
-                     int64_t zstride, float* grads, hipStream_t s, bool split_bf16 = false) {
+                     int64_t zstride, float* grads, hipStream_t s, bool split_bf16 = false, int a_lo = 0, int z_lo = 0) {
   // A job's cost per sample tile = its bytes (nf + kf KiB) + a fixed part (barrier, waits, the 4 DMA issues per wave,
   // transposed reads, MFMAs) worth about 128 KiB of streaming: single-job timings fit t = a (nf + kf + c0) with c0 = 24
   // at a full grid, but under load the sweep over c0 keeps improving up to ~128 and is flat beyond (tools/sweep_dw.py).  Split the sample range of every job in proportion.
@@ -1931,6 +1872,7 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   NERF_REQUIRE(nw <= DW_MAX_WGS, NERF_E_SHAPE, "nerf_mlp_backward: dw_workgroups must be <= %d", DW_MAX_WGS);
   d.ntiles = (int)ntiles; d.astride = astride; d.zstride = zstride;
   d.acts = acts; d.dz = dz; d.grads = grads;
+  d.a_lo = a_lo; d.z_lo = z_lo;
   // the partial-tile slots live behind the dZ fragment blocks in the caller's dz workspace (nerf_mlp_dz_bytes counts them)
   d.partial = reinterpret_cast<float*>(static_cast<char*>(dz) + padded_tiles(ntiles * 32) * zstride * 16);
   int rc;
@@ -1958,12 +1900,19 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   auto s = as_stream(stream);
   const int64_t ntiles = (M + 31) / 32;
   if (arch_kind(arch) == 2) {
-    SmallArgs a;
-    small_args(a, packed);
-    a.d_raw = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M; a.d_x = d_x;
-    const int64_t nwg = (ntiles + 7) / 8;
-    hipLaunchKernelGGL(mlp_small_bwd_kernel, dim3((unsigned)(nwg < 2048 ? nwg : 2048)), dim3(512), LN::LDS_BYTES, s, a);
-    int rcs = check_launch("mlp backward chain (2x64 model)");
+    const bool sp = arch_s16(arch);
+    int rcs;
+    if (sp) {
+      rcs = s16x::small_backward_chain(static_cast<const char*>(packed) + LN::PACKED_BYTES, acts, d_raw, M, dz, d_x,
+                                       small_astride16(true), small_zstride16(true), s);
+    } else {
+      SmallArgs a;
+      small_args(a, packed);
+      a.d_raw = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M; a.d_x = d_x;
+      const int64_t nwg = (ntiles + 7) / 8;
+      hipLaunchKernelGGL(mlp_small_bwd_kernel, dim3((unsigned)(nwg < 2048 ? nwg : 2048)), dim3(512), LN::LDS_BYTES, s, a);
+      rcs = check_launch("mlp backward chain (2x64 model)");
+    }
     if (rcs) return rcs;
     DwArgs ds;
     int njs = 0;
@@ -1977,18 +1926,28 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     jobs(LN::Z_D, 2, LN::A_FEAT, 4, LN::P_WD, 80, 0, 32, 64, LN::P_BD);        // dir0 | feature
     jobs(LN::Z_D, 2, LN::A_DX, 1, LN::P_WD, 80, 64, 32, 16, -1);               // dir0 | direction features
     jobs(LN::Z_RGB, 1, LN::A_HD, 2, LN::P_WR, 32, 0, 3, 32, LN::P_BR);         // rgb
-    return launch_dw(ds, njs, ntiles, LN::P_TOTAL, acts, dz, small_astride16(), small_zstride16(), grads, s);
+    return launch_dw(ds, njs, ntiles, LN::P_TOTAL, acts, dz, small_astride16(sp), small_zstride16(sp), grads, s, sp, s16x::SM_A_LO,
+                     s16x::SM_Z_LO);
   }
   if (arch_kind(arch) == 1) {
-    ImgArgs a;
-    img_args(a, arch, packed);
-    a.d_out = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M;
-    const int64_t nsuper = (ntiles + 7) / 8;
-    static DevOnce once_i;
-    if (once_i.first()) ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES);
-    hipLaunchKernelGGL(mlp_img_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
-                       RING_LDS_BYTES, s, a);
-    int rci = check_launch("mlp backward chain (image model)");
+    if (arch_f32(arch))
+      return f32::backward(static_cast<const char*>(packed) + IMG_BF16_BYTES, acts, d_raw, M, dz, grads, arch->out_ch, s);
+    const bool sp = arch_s16(arch);
+    int rci;
+    if (sp) {
+      rci = s16x::img_backward_chain(static_cast<const char*>(packed) + IMG_BF16_BYTES, acts, d_raw, M, arch->out_ch, dz,
+                                     img_astride16(true), img_zstride16(true), ring_wgs(), s);
+    } else {
+      ImgArgs a;
+      img_args(a, arch, packed);
+      a.d_out = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M;
+      const int64_t nsuper = (ntiles + 7) / 8;
+      static DevOnce once_i;
+      if (once_i.first()) ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES);
+      hipLaunchKernelGGL(mlp_img_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
+                         RING_LDS_BYTES, s, a);
+      rci = check_launch("mlp backward chain (image model)");
+    }
     if (rci) return rci;
     DwArgs di;
     int nji = 0;
@@ -2003,10 +1962,11 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
     jobi(LI::Z_L0 + 96, 16, LI::A_H0 + 80, 16, LI::P_W6, 256, 0, 256, 256, LI::P_B6);                      // pos6
     jobi(LI::Z_L0 + 112, 16, LI::A_H0 + 96, 16, LI::P_W7, 256, 0, 256, 256, LI::P_B7);                     // pos7
     jobi(LI::Z_OUT, 1, LI::A_H0 + 112, 16, LI::P_WO, 256, 0, arch->out_ch, 256, LI::P_WO + arch->out_ch * 256);   // output
-    return launch_dw(di, nji, ntiles, img_params(arch), acts, dz, img_astride16(), img_zstride16(), grads, s);
+    return launch_dw(di, nji, ntiles, img_params(arch), acts, dz, img_astride16(sp), img_zstride16(sp), grads, s, sp, s16x::IMG_A_LO,
+                     s16x::IMG_Z_LO);
   }
   if (arch_f32(arch)) {
-    return f32::backward(packed32_of(packed), acts, d_raw, M, dz, grads, s);
+    return f32::backward(packed32_of(packed), acts, d_raw, M, dz, grads, 0, s);
   }
   const bool split = arch_s16(arch);
   const int64_t astr = split ? s16_astride16() : astride16(), zstr = split ? s16_zstride16() : zstride16();
@@ -2063,7 +2023,7 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   job(L::Z_D, 8, L::A_FEAT, 16, L::P_WD, 283, 0, 128, 256, L::P_BD);                               // dir0 | feature
   job(L::Z_D, 8, L::A_DPE, 2, L::P_WD, 283, 256, 128, 27, -1);                                     // dir0 | dirPE
   job(L::Z_RGB, 1, L::A_HD, 8, L::P_WR, 128, 0, 3, 128, L::P_BR);                                  // rgb
-  return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astr, zstr, grads, s, split);
+  return launch_dw(d, nj, ntiles, L::P_TOTAL, acts, dz, astr, zstr, grads, s, split, s16::A_LO, s16::Z_LO);
 }
 
 extern "C" int nerf_ngp_query_fused_h(const nerf_mlp_arch* arch, const void* packed, const float* rays, const float* z,
@@ -2078,6 +2038,14 @@ extern "C" int nerf_ngp_query_fused_h(const nerf_mlp_arch* arch, const void* pac
   NERF_REQUIRE(packed && rays && z && tables && resolutions_host && raw, NERF_E_NULL, "nerf_ngp_query_fused: NULL pointer");
   const int64_t M = B * n;
   NERF_REQUIRE(M < (1ll << 31), NERF_E_SHAPE, "nerf_ngp_query_fused: B*n must be < 2^31");
+  if (arch_s16(arch)) {         // reference tolerance: float32 gathers from the master tables (the fp16 shadow is a reduced-precision
+    s16x::SmallQuery q;         // image: not read in this mode), float32 interpolation, split-bf16 MLP (mlp_s16x.hip)
+    q.rays = rays; q.z = z; q.n = n; q.tables = tables; q.T = 1u << log2_T; q.pos_scale = pos_scale; q.pos_offset = pos_offset;
+    for (int l = 0; l < 32; ++l) q.res[l] = l < L ? (float)resolutions_host[l] : 0.0f;
+    q.B = B; q.ray_major = g_ngp_ray_major;
+    return s16x::small_forward(static_cast<const char*>(packed) + LN::PACKED_BYTES, small_bias_of(packed), nullptr, M, raw, acts,
+                               small_astride16(true), &q, as_stream(stream));
+  }
   SmallArgs a;
   small_args(a, packed);
   a.out = raw; a.acts = acts; a.M = M; a.rays = rays; a.z = z; a.n = n; a.tables = tables; a.T = 1u << log2_T;
@@ -2131,9 +2099,29 @@ __global__ void __launch_bounds__(256) decode_frags_kernel(const void* base, int
     }
   }
 }
-// (slot, fragments) of `layer` in the activation (kind 0) or dZ (kind 1) store of the 8 x 256 view model
-static bool debug_slot(int kind, int layer, int* slot, int* nfrag) {
-  if (layer < 0 || layer > 11) return false;
+// (slot, fragments) of `layer` in the activation (kind 0) or dZ (kind 1) store of an architecture (arch_kind 0 / 1 / 2)
+static bool debug_slot(int ak, int kind, int layer, int* slot, int* nfrag) {
+  if (layer < 0 || layer > 11 || (kind != 0 && kind != 1)) return false;
+  if (ak == 1) {                       // image model: pos0..7; 8 = output gradient; 10 = input rows (48 = 40 + pad)
+    if (layer < 8) { *slot = (kind == 0 ? LI::A_H0 : LI::Z_L0) + 16 * layer; *nfrag = 16; return true; }
+    if (kind == 0 && layer == 10) { *slot = LI::A_X; *nfrag = 3; return true; }
+    if (kind == 1 && layer == 8) { *slot = LI::Z_OUT; *nfrag = 1; return true; }
+    return false;
+  }
+  if (ak == 2) {                       // 2 x 64 model: pos0, pos1; 8 = feature; 9 = dir0; 10 / 11 = inputs (acts) or d alpha / d rgb (dz)
+    if (kind == 0) {
+      if (layer == 0) { *slot = LN::A_H0; *nfrag = 4; } else if (layer == 1) { *slot = LN::A_H1; *nfrag = 4; }
+      else if (layer == 8) { *slot = LN::A_FEAT; *nfrag = 4; } else if (layer == 9) { *slot = LN::A_HD; *nfrag = 2; }
+      else if (layer == 10) { *slot = LN::A_X; *nfrag = 2; } else if (layer == 11) { *slot = LN::A_DX; *nfrag = 1; }
+      else return false;
+      return true;
+    }
+    if (layer == 0) { *slot = LN::Z_L0; *nfrag = 4; } else if (layer == 1) { *slot = LN::Z_L1; *nfrag = 4; }
+    else if (layer == 8) { *slot = LN::Z_F; *nfrag = 4; } else if (layer == 9) { *slot = LN::Z_D; *nfrag = 2; }
+    else if (layer == 10) { *slot = LN::Z_A; *nfrag = 1; } else if (layer == 11) { *slot = LN::Z_RGB; *nfrag = 1; }
+    else return false;
+    return true;
+  }
   if (kind == 0) {
     if (layer < 8) { *slot = L::A_H0 + 16 * layer; *nfrag = 16; }
     else if (layer == 8) { *slot = L::A_FEAT; *nfrag = 16; }
@@ -2142,40 +2130,43 @@ static bool debug_slot(int kind, int layer, int* slot, int* nfrag) {
     else { *slot = L::A_DPE; *nfrag = 2; }
     return true;
   }
-  if (kind == 1) {
-    if (layer < 8) { *slot = L::Z_L0 + 16 * layer; *nfrag = 16; }
-    else if (layer == 8) { *slot = L::Z_F; *nfrag = 16; }
-    else if (layer == 9) { *slot = L::Z_D; *nfrag = 8; }
-    else if (layer == 10) { *slot = L::Z_A; *nfrag = 1; }
-    else { *slot = L::Z_RGB; *nfrag = 1; }
-    return true;
-  }
-  return false;
+  if (layer < 8) { *slot = L::Z_L0 + 16 * layer; *nfrag = 16; }
+  else if (layer == 8) { *slot = L::Z_F; *nfrag = 16; }
+  else if (layer == 9) { *slot = L::Z_D; *nfrag = 8; }
+  else if (layer == 10) { *slot = L::Z_A; *nfrag = 1; }
+  else { *slot = L::Z_RGB; *nfrag = 1; }
+  return true;
 }
 }  // namespace nerf
 
 extern "C" int nerf_mlp_debug_width(const nerf_mlp_arch* arch, int kind, int layer) {
   int slot = 0, nfrag = 0;
-  if (!arch_ok(arch)) return -1;
+  const int ak = arch_kind(arch);
+  if (ak < 0) return -1;
   if (arch_f32(arch)) return f32::debug_width(kind, layer);
-  if (!debug_slot(kind, layer, &slot, &nfrag)) return -1;
+  if (!debug_slot(ak, kind, layer, &slot, &nfrag)) return -1;
   return 16 * nfrag;
 }
 
 extern "C" int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store, int kind, int layer, int64_t M,
                                    float* out, void* stream) {
-  NERF_ARCH_CHECK("nerf_mlp_debug_read");
+  NERF_ARCH_CHECK_ANY("nerf_mlp_debug_read");
   if (arch_f32(arch)) {
     NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");
     return M <= 0 ? NERF_OK : f32::debug_read(store, kind, layer, M, out, as_stream(stream));
   }
   int slot = 0, nfrag = 0;
-  NERF_REQUIRE(debug_slot(kind, layer, &slot, &nfrag), NERF_E_SHAPE, "nerf_mlp_debug_read: kind must be 0/1 and layer 0..11");
+  const int ak = arch_kind(arch);
+  NERF_REQUIRE(debug_slot(ak, kind, layer, &slot, &nfrag), NERF_E_SHAPE, "nerf_mlp_debug_read: no such (kind, layer) in this architecture's stores");
   NERF_REQUIRE(store && out, NERF_E_NULL, "nerf_mlp_debug_read: NULL pointer");
   if (M <= 0) return NERF_OK;
-  hipLaunchKernelGGL(decode_frags_kernel, dim3(grid_for(M * nfrag * 2, 256)), dim3(256), 0, as_stream(stream), store,
-                     arch_s16(arch) ? (kind == 0 ? s16_astride16() : s16_zstride16()) : (kind == 0 ? astride16() : zstride16()), slot, nfrag,
-                     M, out, arch_s16(arch) ? (kind == 0 ? s16::A_LO : s16::Z_LO) : 0);
+  const bool sp = arch_s16(arch);
+  const int64_t stride = ak == 0 ? (sp ? (kind == 0 ? s16_astride16() : s16_zstride16()) : (kind == 0 ? astride16() : zstride16()))
+                         : ak == 1 ? (kind == 0 ? img_astride16(sp) : img_zstride16(sp)) : (kind == 0 ? small_astride16(sp) : small_zstride16(sp));
+  const int lo_off = !sp ? 0 : ak == 0 ? (kind == 0 ? s16::A_LO : s16::Z_LO) : ak == 1 ? (kind == 0 ? s16x::IMG_A_LO : s16x::IMG_Z_LO)
+                                                                                     : (kind == 0 ? s16x::SM_A_LO : s16x::SM_Z_LO);
+  hipLaunchKernelGGL(decode_frags_kernel, dim3(grid_for(M * nfrag * 2, 256)), dim3(256), 0, as_stream(stream), store, stride, slot, nfrag,
+                     M, out, lo_off);
   return check_launch("nerf_mlp_debug_read");
 }
 

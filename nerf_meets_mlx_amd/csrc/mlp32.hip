@@ -24,6 +24,7 @@
 //    revolution-sine of the bf16 path.
 #include "common.h"
 #include "mlp_params.h"
+#include "mlp_arch2.h"
 #include "mlp32.h"
 #include <type_traits>
 #include <utility>
@@ -41,8 +42,10 @@ __host__ __device__ constexpr int prow(int i) { return (i & 3) + 8 * (i >> 2); }
 // tail of the packed image (floats)
 constexpr int T_B = 0;              // pos biases, 256 l
 constexpr int T_BF = 2048, T_BD = 2304, T_BA = 2432, T_BR = 2433, T_WA = 2440, T_WR = 2696;
-constexpr int BIAS_FLOATS = T_WR + 384;   // the forward keeps the whole tail in LDS (biases, alpha and rgb heads)
-static_assert(T_WR + 384 <= TAIL_FLOATS, "tail too small");
+// image model (no view head): output_linear [out_ch <= 4][256] at T_WO, its bias at T_BO (the view heads' slots are unused there)
+constexpr int T_BO = T_BA, T_WO = T_WA;
+constexpr int BIAS_FLOATS = T_WO + 1024;  // the forward keeps the whole tail in LDS (biases, alpha and rgb heads | output head)
+static_assert(T_WR + 384 <= BIAS_FLOATS && BIAS_FLOATS <= TAIL_FLOATS, "tail too small");
 // forward stream fragment bases
 constexpr int F_L0 = 0, F_L1 = 16, F_L5 = 272, F_L6 = 352, F_FEAT = 480, F_DIR = 544;
 static_assert(F_DIR + 36 == F_FRAGS, "forward stream");
@@ -56,24 +59,28 @@ constexpr int Z_L0 = 0, Z_F = 2048, Z_D = 2304, Z_A = 2432, Z_RGB = 2464;
 static_assert(A_HD + 128 == A_MASK && A_MASK + 64 == A_ROWS && Z_RGB + 32 == Z_ROWS, "store rows");
 
 // ------------------------------------------------------------------------------------------ packing
-__device__ float fwd_src(const float* __restrict__ p, int f, int n32, int kk) {
+// img: the image-fitting model (entrypoints/__viser_image_learning.py:203-208: input 40, pos5 [256 x 296], no view head) uses the
+// trunk part of the same streams (forward fragments [0, F_FEAT), transposed fragments [B_POS, B_FRAGS)); the rest stays zero
+__device__ float fwd_src(const float* __restrict__ p, int f, int n32, int kk, bool img) {
+  const int cin = img ? LI::CIN : 63, ld5 = 256 + cin;
   if (f < F_L1) {
     const int nt = f / 2, kt = f % 2, k = 32 * kt + kk;
-    return k < 63 ? p[L::P_W0 + (32 * nt + n32) * 63 + k] : 0.0f;
+    return k < cin ? p[(img ? LI::P_W0 : L::P_W0) + (32 * nt + n32) * cin + k] : 0.0f;
   }
   if (f < F_L5) {
     const int q = f - F_L1, l = 1 + q / 64, r = q % 64;
-    return p[L::pw(l) + (32 * (r / 8) + n32) * 256 + 32 * (r % 8) + kk];
+    return p[(img ? LI::pw(l) : L::pw(l)) + (32 * (r / 8) + n32) * 256 + 32 * (r % 8) + kk];
   }
   if (f < F_L6) {
-    const int q = f - F_L5, n = 32 * (q / 10) + n32, kt = q % 10;
-    if (kt < 2) { const int k = 32 * kt + kk; return k < 63 ? p[L::P_W5 + n * 319 + k] : 0.0f; }
-    return p[L::P_W5 + n * 319 + 63 + 32 * (kt - 2) + kk];
+    const int q = f - F_L5, n = 32 * (q / 10) + n32, kt = q % 10, w5 = img ? LI::P_W5 : L::P_W5;
+    if (kt < 2) { const int k = 32 * kt + kk; return k < cin ? p[w5 + n * ld5 + k] : 0.0f; }
+    return p[w5 + n * ld5 + cin + 32 * (kt - 2) + kk];
   }
   if (f < F_FEAT) {
     const int q = f - F_L6, l = 6 + q / 64, r = q % 64;
-    return p[L::pw(l) + (32 * (r / 8) + n32) * 256 + 32 * (r % 8) + kk];
+    return p[(img ? LI::pw(l) : L::pw(l)) + (32 * (r / 8) + n32) * 256 + 32 * (r % 8) + kk];
   }
+  if (img) return 0.0f;
   if (f < F_DIR) {
     const int q = f - F_FEAT;
     return p[L::P_WF + (32 * (q / 8) + n32) * 256 + 32 * (q % 8) + kk];
@@ -83,14 +90,20 @@ __device__ float fwd_src(const float* __restrict__ p, int f, int n32, int kk) {
   return kk < 27 ? p[L::P_WD + n * 283 + 256 + kk] : 0.0f;
 }
 // transposed: A row = input feature 32 kt + k32, K index = output feature nn
-__device__ float bwd_src(const float* __restrict__ p, int f, int k32, int kk) {
+__device__ float bwd_src(const float* __restrict__ p, int f, int k32, int kk, bool img) {
+  if (img) {
+    if (f < B_POS) return 0.0f;
+    const int q = f - B_POS, l = 7 - q / 64, r = q % 64, kt = r / 8, ns = r % 8, nn = 32 * ns + kk, row = 32 * kt + k32;
+    return l == 5 ? p[LI::P_W5 + nn * 296 + 40 + row] : p[LI::pw(l) + nn * 256 + row];
+  }
   if (f < B_FEAT) { const int kt = f / 4, ns = f % 4; return p[L::P_WD + (32 * ns + kk) * 283 + 32 * kt + k32]; }
   if (f < B_POS) { const int q = f - B_FEAT, kt = q / 8, ns = q % 8; return p[L::P_WF + (32 * ns + kk) * 256 + 32 * kt + k32]; }
   const int q = f - B_POS, l = 7 - q / 64, r = q % 64, kt = r / 8, ns = r % 8, nn = 32 * ns + kk, row = 32 * kt + k32;
   return l == 5 ? p[L::P_W5 + nn * 319 + 63 + row] : p[L::pw(l) + nn * 256 + row];
 }
 
-__global__ void __launch_bounds__(256) pack32_kernel(const float* __restrict__ p, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) pack32_kernel(const float* __restrict__ p, float* __restrict__ out, int img_out_ch) {
+  const bool img = img_out_ch > 0;
   const int tid = blockIdx.x * 256 + threadIdx.x;
   const int nfl = (F_FRAGS + B_FRAGS) * 64;
   if (tid < nfl) {
@@ -99,12 +112,17 @@ __global__ void __launch_bounds__(256) pack32_kernel(const float* __restrict__ p
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int kk = prow(i) + 4 * h;
-      dst[i] = f < F_FRAGS ? fwd_src(p, f, r, kk) : bwd_src(p, f - F_FRAGS, r, kk);
+      dst[i] = f < F_FRAGS ? fwd_src(p, f, r, kk, img) : bwd_src(p, f - F_FRAGS, r, kk, img);
     }
   } else if (tid < nfl + TAIL_FLOATS) {
     const int t = tid - nfl;
     float v = 0.0f;
-    if (t < T_BF) v = p[L::pb(t >> 8) + (t & 255)];
+    if (img) {
+      if (t < T_BF) v = p[LI::pb(t >> 8) + (t & 255)];
+      else if (t >= T_BO && t < T_BO + img_out_ch) v = p[LI::P_WO + img_out_ch * 256 + (t - T_BO)];
+      else if (t >= T_WO && t < T_WO + img_out_ch * 256) v = p[LI::P_WO + (t - T_WO)];
+    }
+    else if (t < T_BF) v = p[L::pb(t >> 8) + (t & 255)];
     else if (t < T_BD) v = p[L::P_BF + (t - T_BF)];
     else if (t < T_BA) v = p[L::P_BD + (t - T_BD)];
     else if (t == T_BA) v = p[L::P_BA];
@@ -297,6 +315,7 @@ struct FwdArgs32 {
   int64_t M; int n;
   float fpos[10], fdir[4];
   float* out; float* acts;
+  int out_ch;            // image model: columns of `out` (1..4)
 };
 
 // channel c of the embedding [x, sin(f0 x), cos(f0 x), ...] (models/embedding.py:30-71), c >= limit -> 0
@@ -333,7 +352,7 @@ __device__ __forceinline__ f32x16 embed_tile(const float (&v)[3], const float (&
   return embed_tile_impl<KT, LIMIT, NB, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(v, fr, h);
 }
 
-template <bool STORE>
+template <bool STORE, bool IMG>
 __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
@@ -349,7 +368,18 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
   const float4* wl = a.wf + lane * 4;
   int64_t m = tile * 32 + col; if (m >= a.M) m = a.M - 1;
   f32x16 pe[2], dpe[1];
-  if (a.x) {
+  if (IMG) {                                                           // embedded rows [M,40] only (no fused encoding)
+    const float* row = a.x + m * LI::CIN;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int c = 32 * kt + prow(i) + 4 * h; pe[kt][i] = c < LI::CIN ? row[c] : 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dpe[0][i] = 0.0f;
+    // the row loads are complete before the first store below is issued: hipcc otherwise interleaves them and counts the
+    // younger STORES into its vmcnt waits, which is not safe on this chip (frag_wait_n; tools/check_inflight_regs.py flags it)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pe[0]), "+v"(pe[1]) :: "memory");
+  } else if (a.x) {
     const float* row = a.x + m * 90;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -375,8 +405,10 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) *store_row(a.acts, tile, A_ROWS, A_PE + 32 * kt + prow(i) + 4 * h, col) = pe[kt][i];
+    if (!IMG) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) *store_row(a.acts, tile, A_ROWS, A_DPE + prow(i) + 4 * h, col) = dpe[0][i];
+      for (int i = 0; i < 16; ++i) *store_row(a.acts, tile, A_ROWS, A_DPE + prow(i) + 4 * h, col) = dpe[0][i];
+    }
   }
   f32x16 hcur[8];
   layer_fwd<2, true, 2>(wl, F_L0, bias_lds + T_B, 8, pe, slab, col, h, nullptr, 0, bits_of(0));
@@ -396,6 +428,29 @@ __global__ void __launch_bounds__(256) mlp32_fwd_kernel(FwdArgs32 a) {
   for (int l = 6; l <= 7; ++l) {
     layer_fwd<8, true, 4>(wl, F_L6 + (l - 6) * 64, bias_lds + T_B + 256 * l, 8, hcur, slab, col, h, rows_of(A_H0 + 256 * (l - 1)), 256, bits_of(l));
     slab_to_regs<8>(slab, hcur, col, h);
+  }
+  if (IMG) {
+    // output_linear(h7) (models/NeRF.py:196-197,241): out_ch <= 4 dot products per sample on the vector ALU
+    float o4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < a.out_ch) {                                               // wave-uniform
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o4[c] += bias_lds[T_WO + c * 256 + 32 * kt + prow(i) + 4 * h] * hcur[kt][i];
+        o4[c] += __shfl_xor(o4[c], 32, 64);
+        o4[c] += bias_lds[T_BO + c];
+      }
+    }
+    if (STORE) slab_to_store(slab, rows_of(A_H0 + 256 * 7), 256);     // H7's rows: no further layer carries them
+    const int64_t mo = tile * 32 + col;
+    if (h == 0 && mo < a.M) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < a.out_ch) a.out[mo * a.out_ch + c] = o4[c];
+    }
+    return;
   }
   // alpha = Linear(256, 1)(h7): a dot product per sample on the vector ALU (models/NeRF.py:230)
   float alpha = 0.0f;
@@ -440,6 +495,7 @@ struct BwdArgs32 {
   const float4* wb; const float* tail;
   const float* acts; const float* d_raw; int64_t M;
   float* dz;
+  int out_ch;            // image model: columns of d_raw (1..4)
 };
 
 // dZ rows [32 kt + p(i) + 4 h] = mask(W^T[kt-tile] . in (+ extra)) for kt < KT -> the wave's LDS slab.
@@ -500,6 +556,7 @@ __device__ __forceinline__ void layer_bwd(const float4* __restrict__ wl, int fba
   for (int step = KT * NS; step < df.n; ++step) df.store_and_fetch(step);       // (not taken: KT NS >= prev_rows / 8)
 }
 
+template <bool IMG>
 __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
@@ -507,14 +564,58 @@ __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
   const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
   float* wa_lds = slab_smem + 4 * 256 * 32;               // the alpha head's weights (rank-1 term of dZ7): see bias_lds
   float* wr_lds = wa_lds + 256;                           // the rgb head's weights [3][128]
-  wa_lds[threadIdx.x] = a.tail[T_WA + threadIdx.x];
-  for (int i = threadIdx.x; i < 384; i += 256) wr_lds[i] = a.tail[T_WR + i];
+  if (IMG) {                                              // image model: output_linear's weights [4][256] in the same 1024 floats
+    for (int i = threadIdx.x; i < 1024; i += 256) wa_lds[i] = a.tail[T_WO + i];
+  } else {
+    wa_lds[threadIdx.x] = a.tail[T_WA + threadIdx.x];
+    for (int i = threadIdx.x; i < 384; i += 256) wr_lds[i] = a.tail[T_WR + i];
+  }
   __syncthreads();
   if (tile >= ntiles) return;
   float* slab = slab_smem + wv * (256 * 32);
   const float4* wl = a.wb + lane * 4;
   const int64_t m = tile * 32 + col;
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto zrows = [&](int row0) -> float* { return store_row(a.dz, tile, Z_ROWS, row0, 0); };
+  auto bits_of = [&](int l) -> const uint4* {
+    return reinterpret_cast<const uint4*>(store_row(const_cast<float*>(a.acts), tile, A_ROWS, A_MASK + 8 * l, 0)) + lane;
+  };
+  if (IMG) {
+    if (m < a.M) {
+      const float* gr = a.d_raw + m * a.out_ch;
+      g.x = gr[0];
+      if (a.out_ch > 1) g.y = gr[1];
+      if (a.out_ch > 2) g.z = gr[2];
+      if (a.out_ch > 3) g.w = gr[3];
+    }
+    // d out (rows 0..3 of the Z_RGB block; the dW job reads out_ch of them)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = prow(i) + 4 * h;
+      *store_row(a.dz, tile, Z_ROWS, Z_RGB + row, col) = row == 0 ? g.x : row == 1 ? g.y : row == 2 ? g.z : row == 3 ? g.w : 0.0f;
+    }
+    // dZ7 = relu'(H7) * (Wo^T d out): <= 4 terms per unit on the vector ALU, ReLU' from the forward's sign bits (layer_fwd)
+    const uint4 mw = *bits_of(7);
+    const unsigned mws[4] = {mw.x, mw.y, mw.z, mw.w};
+    f32x16 z7[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      const unsigned bits = mws[kt >> 1] >> (16 * (kt & 1));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * kt + prow(i) + 4 * h;
+        const float v = wa_lds[row] * g.x + wa_lds[256 + row] * g.y + wa_lds[512 + row] * g.z + wa_lds[768 + row] * g.w;
+        z7[kt][i] = (bits >> i) & 1u ? v : 0.0f;
+        slab[row * 32 + col] = z7[kt][i];
+      }
+    }
+    for (int l = 7; l >= 1; --l) {                                 // dZ_{l-1} = relu'(H_{l-1}) * (W_l^T dZ_l)   (stores dZ_l)
+      layer_bwd<8>(wl, B_POS + 64 * (7 - l), 8, z7, slab, col, h, bits_of(l - 1), nullptr, 0.0f, zrows(Z_L0 + 256 * l), 256);
+      slab_to_regs<8>(slab, z7, col, h);
+    }
+    slab_to_store(slab, zrows(Z_L0), 256);                          // dZ_0
+    return;
+  }
   if (m < a.M) g = *reinterpret_cast<const float4*>(a.d_raw + m * 4);
   // d rgb (rows 0..2) and d alpha (row 0) blocks of the dz store; the other rows of those 32-row blocks are zero
 #pragma unroll
@@ -546,11 +647,7 @@ __global__ void __launch_bounds__(256) mlp32_bwd_kernel(BwdArgs32 a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) *store_row(a.dz, tile, Z_ROWS, Z_D + 32 * kt + prow(i) + 4 * h, col) = zd[kt][i];
   f32x16 zc[8];
-  auto zrows = [&](int row0) -> float* { return store_row(a.dz, tile, Z_ROWS, row0, 0); };
   // every chain step leaves its rows in the slab; the NEXT step stores them while it computes, the last one at the end
-  auto bits_of = [&](int l) -> const uint4* {
-    return reinterpret_cast<const uint4*>(store_row(const_cast<float*>(a.acts), tile, A_ROWS, A_MASK + 8 * l, 0)) + lane;
-  };
   layer_bwd<4>(wl, B_DIR, 8, zd, slab, col, h, nullptr, nullptr, 0.0f, nullptr, 0);                                         // d feature
   slab_to_regs<8>(slab, zc, col, h);
   layer_bwd<8>(wl, B_FEAT, 8, zc, slab, col, h, bits_of(7), wa_lds, g.w, zrows(Z_F), 256);                                  // dZ7 (stores d feature)
@@ -750,7 +847,7 @@ static bool debug_slot(int kind, int layer, int* row0, int* width) {
 
 // ------------------------------------------------------------------------------------------ host entry points
 constexpr int SLAB_BYTES = 4 * 256 * 32 * 4;        // 128 KiB: one 32 KiB slab per wave
-constexpr int FWD_LDS_BYTES = SLAB_BYTES + BIAS_FLOATS * 4, BWD_LDS_BYTES = SLAB_BYTES + (256 + 384) * 4;
+constexpr int FWD_LDS_BYTES = SLAB_BYTES + BIAS_FLOATS * 4, BWD_LDS_BYTES = SLAB_BYTES + 1024 * 4;
 
 // opt in to more than 64 KiB of dynamic LDS, once per (kernel, device).  Keyed by the kernel's ADDRESS: the two forward
 // instantiations have the same function type, so a per-type flag (the first version) served only whichever ran first.
@@ -767,9 +864,9 @@ static void want_lds(K kernel, int bytes = SLAB_BYTES) {
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int pack(const float* params, void* packed32, hipStream_t s) {
+int pack(const float* params, void* packed32, int img_out_ch, hipStream_t s) {
   const int total = (F_FRAGS + B_FRAGS) * 64 + TAIL_FLOATS;
-  hipLaunchKernelGGL(pack32_kernel, dim3((total + 255) / 256), dim3(256), 0, s, params, static_cast<float*>(packed32));
+  hipLaunchKernelGGL(pack32_kernel, dim3((total + 255) / 256), dim3(256), 0, s, params, static_cast<float*>(packed32), img_out_ch);
   return check_launch("nerf_mlp_pack (fp32 streams)");
 }
 
@@ -778,8 +875,9 @@ static const float* tail_of(const void* packed32) {
 }
 
 int forward(const void* packed32, const float* x, const float* rays, const float* z, int64_t M, int n, int freq_mode,
-            float* out, void* acts, hipStream_t s) {
+            float* out, void* acts, int img_out_ch, hipStream_t s) {
   FwdArgs32 a;
+  a.out_ch = img_out_ch;
   a.wf = static_cast<const float4*>(packed32);
   a.tail = tail_of(packed32);
   a.x = x; a.rays = rays; a.z = z; a.M = M; a.n = n; a.out = out; a.acts = static_cast<float*>(acts);
@@ -787,25 +885,42 @@ int forward(const void* packed32, const float* x, const float* rays, const float
   for (int k = 0; k < 4; ++k) a.fdir[k] = freq_mode == 0 ? (float)(k * k) : (float)(1 << k);
   const int64_t blocks = (tiles_of(M) + 3) / 4;
   NERF_REQUIRE(blocks < (1ll << 31), NERF_E_SHAPE, "mlp forward (fp32): M too large");
-  if (acts) {
-    want_lds(mlp32_fwd_kernel<true>, FWD_LDS_BYTES);
-    hipLaunchKernelGGL(mlp32_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
+  if (img_out_ch > 0) {
+    NERF_REQUIRE(x && img_out_ch <= 4, NERF_E_SHAPE, "mlp forward (fp32, image model): needs embedded rows and out_ch <= 4");
+    if (acts) {
+      want_lds((mlp32_fwd_kernel<true, true>), FWD_LDS_BYTES);
+      hipLaunchKernelGGL((mlp32_fwd_kernel<true, true>), dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
+    } else {
+      want_lds((mlp32_fwd_kernel<false, true>), FWD_LDS_BYTES);
+      hipLaunchKernelGGL((mlp32_fwd_kernel<false, true>), dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
+    }
+  } else if (acts) {
+    want_lds((mlp32_fwd_kernel<true, false>), FWD_LDS_BYTES);
+    hipLaunchKernelGGL((mlp32_fwd_kernel<true, false>), dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
   } else {
-    want_lds(mlp32_fwd_kernel<false>, FWD_LDS_BYTES);
-    hipLaunchKernelGGL(mlp32_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
+    want_lds((mlp32_fwd_kernel<false, false>), FWD_LDS_BYTES);
+    hipLaunchKernelGGL((mlp32_fwd_kernel<false, false>), dim3((unsigned)blocks), dim3(256), FWD_LDS_BYTES, s, a);
   }
   return check_launch("mlp forward (fp32)");
 }
 
-int backward(const void* packed32, const void* acts, const float* d_raw, int64_t M, void* dz, float* grads, hipStream_t s) {
+int backward(const void* packed32, const void* acts, const float* d_raw, int64_t M, void* dz, float* grads, int img_out_ch,
+             hipStream_t s) {
   BwdArgs32 b;
+  b.out_ch = img_out_ch;
+  const bool img = img_out_ch > 0;
   b.wb = reinterpret_cast<const float4*>(static_cast<const char*>(packed32) + (size_t)F_FRAGS * FRAG_BYTES);
   b.tail = tail_of(packed32);
   b.acts = static_cast<const float*>(acts); b.d_raw = d_raw; b.M = M; b.dz = static_cast<float*>(dz);
   const int64_t ntiles = tiles_of(M), blocks = (ntiles + 3) / 4;
   NERF_REQUIRE(blocks < (1ll << 31), NERF_E_SHAPE, "mlp backward (fp32): M too large");
-  want_lds(mlp32_bwd_kernel, BWD_LDS_BYTES);
-  hipLaunchKernelGGL(mlp32_bwd_kernel, dim3((unsigned)blocks), dim3(256), BWD_LDS_BYTES, s, b);
+  if (img) {
+    want_lds(mlp32_bwd_kernel<true>, BWD_LDS_BYTES);
+    hipLaunchKernelGGL(mlp32_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), BWD_LDS_BYTES, s, b);
+  } else {
+    want_lds(mlp32_bwd_kernel<false>, BWD_LDS_BYTES);
+    hipLaunchKernelGGL(mlp32_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), BWD_LDS_BYTES, s, b);
+  }
   int rc = check_launch("mlp backward chain (fp32)");
   if (rc) return rc;
   DwArgs32 d;
@@ -813,6 +928,15 @@ int backward(const void* packed32, const void* acts, const float* d_raw, int64_t
   auto job = [&](int zrow0, int n_rows, int arow0, int k_rows, int w_off, int ldw, int col0, int nv, int kv, int b_off) {
     d.jobs[nj++] = DwJob32{zrow0, n_rows / 32, arow0, k_rows / 32, w_off, ldw, col0, nv, kv, b_off};
   };
+  if (img) {
+    job(Z_L0, 256, A_PE, 64, LI::P_W0, 40, 0, 256, 40, LI::P_B0);                                          // pos0
+    for (int l = 1; l <= 4; ++l) job(Z_L0 + 256 * l, 256, A_H0 + 256 * (l - 1), 256, LI::pw(l), 256, 0, 256, 256, LI::pb(l));
+    job(Z_L0 + 256 * 5, 256, A_H0 + 256 * 4, 256, LI::P_W5, 296, 40, 256, 256, LI::P_B5);                  // pos5 | H4
+    job(Z_L0 + 256 * 5, 256, A_PE, 64, LI::P_W5, 296, 0, 256, 40, -1);                                     // pos5 | x
+    job(Z_L0 + 256 * 6, 256, A_H0 + 256 * 5, 256, LI::P_W6, 256, 0, 256, 256, LI::P_B6);
+    job(Z_L0 + 256 * 7, 256, A_H0 + 256 * 6, 256, LI::P_W7, 256, 0, 256, 256, LI::P_B7);
+    job(Z_RGB, 32, A_H0 + 256 * 7, 256, LI::P_WO, 256, 0, img_out_ch, 256, LI::P_WO + img_out_ch * 256);   // output_linear
+  } else {
   job(Z_L0, 256, A_PE, 64, L::P_W0, 63, 0, 256, 63, L::P_B0);                                              // pos0
   for (int l = 1; l <= 4; ++l) job(Z_L0 + 256 * l, 256, A_H0 + 256 * (l - 1), 256, L::pw(l), 256, 0, 256, 256, L::pb(l));
   job(Z_L0 + 256 * 5, 256, A_H0 + 256 * 4, 256, L::P_W5, 319, 63, 256, 256, L::P_B5);                      // pos5 | H4
@@ -824,6 +948,7 @@ int backward(const void* packed32, const void* acts, const float* d_raw, int64_t
   job(Z_D, 128, A_FEAT, 256, L::P_WD, 283, 0, 128, 256, L::P_BD);                                          // dir0 | feature
   job(Z_D, 128, A_DPE, 32, L::P_WD, 283, 256, 128, 27, -1);                                                // dir0 | dirPE
   job(Z_RGB, 32, A_HD, 128, L::P_WR, 128, 0, 3, 128, L::P_BR);                                             // rgb
+  }
   int blocks_total = 0;
   for (int j = 0; j < nj; ++j) blocks_total += ((d.jobs[j].n_tiles + 1) / 2) * ((d.jobs[j].k_tiles + 1) / 2);
   int splits = 2048 / blocks_total;                      // about two waves per SIMD of a 256-CU device

@@ -68,9 +68,14 @@ class HashNeRF:
 
     def __init__(self, device="cuda", seed: int = 0, n_levels: int = 16, min_res: int = 16, max_res: int = 2048,
                  n_features_per_level: int = 2, log2_hashmap_size: int = 19, hash_init_scale: float = 1e-4,
-                 bound: Optional[float] = 1.5, deterministic: bool = True, level_groups: int = 4, half_tables: bool = True):
-        """half_tables: the fused query gathers from an fp16 shadow image of the tables (half the gather bytes; float32 master,
-        float32 interpolation; the MLP rounds the interpolated features to bf16 anyway) -- SURVEY 8(d)'s 512 B per sample.
+                 bound: Optional[float] = 1.5, deterministic: bool = True, level_groups: int = 4,
+                 half_tables: Optional[bool] = None, precision: int = 22):
+        """precision: arithmetic of the 2 x 64 network (`NeRF(precision=...)`).  22 (default): the reference's float32 tolerance
+        -- float32 gathers from the master tables, float32 interpolation (encoding/multi_hash.py:112-131), split-bf16 MLP
+        (csrc/mlp_s16x.hip); 16: the declared reduced-precision mode (bf16 MLP operands, interpolated features rounded to bf16).
+        half_tables (precision 16 only; default on there): the fused query gathers from an fp16 shadow image of the tables (half
+        the gather bytes; float32 master, float32 interpolation; the bf16 MLP rounds the interpolated features to 8 bits anyway)
+        -- SURVEY 8(d)'s 512 B per sample.  Refused at precision 22, whose point is not to round the features.
         bound: half-extent of the scene box that is mapped onto the grid's unit cube before hashing
         (x' = (x + bound) / (2 bound)), so that N_l is the level's resolution ACROSS the scene (without it the reference's
         x * N_l sees world units: 3 x finer cells, and a 24-view run memorises its training rays: held-out PSNR 13.8 dB
@@ -80,7 +85,12 @@ class HashNeRF:
                                      hash_init_scale, device=device, seed=seed)
         self.sh = SphericalHarmonicsEncoding(3, 3)
         self.mlp = NeRF(n_layers=2, width_layers=64, channel_input=32, channel_input_views=16,
-                        list_skip_connection_layers=[], is_use_view_directions=True, device=device, seed=seed)
+                        list_skip_connection_layers=[], is_use_view_directions=True, device=device, seed=seed, precision=precision)
+        self.precision = int(precision)
+        if half_tables is None:
+            half_tables = self.precision == 16
+        if half_tables and self.precision != 16:
+            raise ValueError("HashNeRF: half_tables (fp16 shadow gathers) is a reduced-precision option of precision=16")
         self.pos_scale, self.pos_offset = (1.0, 0.0) if bound is None else (1.0 / (2.0 * bound), 0.5)
         # table-gradient accumulator: int64 2^-52 fixed point added with integer atomics (the default: bit-reproducible, and
         # measured no slower than float atomics -- both are bound by the atomic request rate, profiles/r03_ngp_scatter.csv)
@@ -190,13 +200,14 @@ class NGPTrainer(Trainer):
 
     def __init__(self, images, poses, K, near: float = 2.0, far: float = 6.0, N_rand: int = 4096,
                  n_depth_samples: int = 64, lrate: float = 5e-4, lrate_decay: int = 500, white_bkgd: bool = True,
-                 seed: int = 0, device="cuda", chunk: int = 1024 * 32, table_sync: str = "shard", **hash_kw):
+                 seed: int = 0, device="cuda", chunk: int = 1024 * 32, table_sync: str = "shard", precision: int = 22,
+                 **hash_kw):
         super().__init__(images, poses, K, near=near, far=far, N_rand=N_rand, n_depth_samples=n_depth_samples,
                          N_importance=0, lrate=lrate, lrate_decay=lrate_decay, white_bkgd=white_bkgd, ref_quirks=True,
-                         seed=seed, device=device, chunk=chunk)
+                         seed=seed, device=device, chunk=chunk, precision=precision)
         self.coarse = None                                   # the 8 x 256 network of the base class is not used
-        self.field = HashNeRF(device=self.device, seed=seed, **hash_kw)
-        self.field.mlp.name = "mlp"
+        self._field = HashNeRF(device=self.device, seed=seed, precision=precision, **hash_kw)
+        self._field.mlp.name = "mlp"
         # Adam WITH bias correction: without it the first steps are lr * sign(g), which turns bf16 noise in near-zero
         # table gradients into full-size steps and can drive sigma negative everywhere (a dead network under the
         # reference's un-activated sigma).  This loop is our wiring, so the choice is ours; lrate is
@@ -210,19 +221,34 @@ class NGPTrainer(Trainer):
         #                the owned shards only, all-gather of the updated float32 tables: 134 (W-1)/W + 67 (W-1)/W MB instead of
         #                2 x 134 (W-1)/W, a W-th of the Adam work, and exact integer sums as before (bit-identical tables on all
         #                ranks, run to run, and identical to the all-reduce schedule).  Adam moments are sharded with the
-        #                parameters: state_dict() gathers them (a collective: every rank must call it).
+        #                parameters: `sync_optimizer_state()` gathers them -- an explicit COLLECTIVE every rank calls at the same
+        #                iteration; state_dict() / save() never communicate and RAISE while the moments are stale, so the
+        #                usual "if rank == 0: save()" idiom cannot hang in a collective the other ranks never enter.
         if table_sync not in ("shard", "allreduce"):
             raise ValueError("NGPTrainer: table_sync must be 'shard' or 'allreduce'")
-        per_group = [(hi - lo) * self.field.enc.hash_table_size * self.field.enc.n_features_per_level for lo, hi in self.field.level_groups]
+        per_group = [(hi - lo) * self._field.enc.hash_table_size * self._field.enc.n_features_per_level for lo, hi in self._field.level_groups]
         self.table_sync = table_sync if (self.world > 1 and all(n % self.world == 0 for n in per_group)) else "allreduce"
         self._rs_bufs = None
+        self._moments_synced = True          # no step taken yet: nothing sharded
+
+    # `field` (tables, MLP) may still be receiving the other ranks' updated shards on the comm stream when train_step returns:
+    # reading it from outside joins that stream first (a stream-side wait, no host block).  The hot loop uses _field.
+    @property
+    def field(self):
+        self._join_comm()
+        return self._field
+
+    @field.setter
+    def field(self, f):
+        self._field = f
 
     def train_step(self, rays=None, target=None, u=None) -> Dict[str, torch.Tensor]:
         if rays is None:
             rays, target = self.sample_batch()
         self._opt.learning_rate = self.lrate * (0.1 ** (self.it / (self.lrate_decay * 1000)))
         z = sampling.sample_coarse(rays, self.n)
-        raw = self.field.query(rays, z, train=True)
+        self._join_comm()                                    # the previous step's table all-gathers (sharded updates)
+        raw = self._field.query(rays, z, train=True)
         loss, d_raw, _ = render.composite_mse_backward(raw, z, rays, target, self.white_bkgd)
         pending, mlp_work = [], []
         shard = self.world > 1 and self.table_sync == "shard"
@@ -231,8 +257,8 @@ class NGPTrainer(Trainer):
             # before the scatters start), then each level group's slice of the table gradient as soon as its scatter is
             # enqueued -- all on the comm stream, behind events: the transfers overlap the following groups' scatters,
             # and the MLP Adam runs while the table slices are still on the wire.
-            per_level = self.field.enc.hash_table_size * self.field.enc.n_features_per_level
-            flat = self.field.table.grads
+            per_level = self._field.enc.hash_table_size * self._field.enc.n_features_per_level
+            flat = self._field.table.grads
 
             def on_comm(t):
                 ev = torch.cuda.Event()
@@ -240,29 +266,29 @@ class NGPTrainer(Trainer):
                 self._comm.wait_event(ev)
                 with torch.cuda.stream(self._comm):
                     return torch.distributed.all_reduce(t, async_op=True)
-            self.field.on_mlp_grads = lambda g: mlp_work.append(on_comm(g))
+            self._field.on_mlp_grads = lambda g: mlp_work.append(on_comm(g))
             if shard:
                 if self._rs_bufs is None or self._rs_bufs[0].dtype != flat.dtype:
                     self._rs_bufs = [torch.empty((hi - lo) * per_level // self.world, dtype=flat.dtype, device=flat.device)
-                                     for lo, hi in self.field.level_groups]
+                                     for lo, hi in self._field.level_groups]
 
                 def on_group(lo, hi):
-                    gi = self.field.level_groups.index((lo, hi))
+                    gi = self._field.level_groups.index((lo, hi))
                     ev = torch.cuda.Event()
                     ev.record()
                     self._comm.wait_event(ev)
                     with torch.cuda.stream(self._comm):
                         pending.append(torch.distributed.reduce_scatter_tensor(self._rs_bufs[gi], flat[lo * per_level:hi * per_level],
                                                                                async_op=True))
-                self.field.on_group_done = on_group
+                self._field.on_group_done = on_group
             else:
-                self.field.on_group_done = lambda lo, hi: pending.append(on_comm(flat[lo * per_level:hi * per_level]))
+                self._field.on_group_done = lambda lo, hi: pending.append(on_comm(flat[lo * per_level:hi * per_level]))
         # accumulate (no clear) only when the accumulator is KNOWN to be zero: left so by the previous step's table Adam
-        g_mlp, g_tab = self.field.backward(d_raw, accumulate=self.field._grad_clean)
-        self.field.on_group_done = self.field.on_mlp_grads = None
+        g_mlp, g_tab = self._field.backward(d_raw, accumulate=self._field._grad_clean)
+        self._field.on_group_done = self._field.on_mlp_grads = None
         for w in mlp_work:
             w.wait()
-        self._opt.update(self.field.mlp, g_mlp, grad_scale=1.0 / self.world)      # _opt: the `opt` property would join the comm stream
+        self._opt.update(self._field.mlp, g_mlp, grad_scale=1.0 / self.world)      # _opt: the `opt` property would join the comm stream
         for w in pending:
             w.wait()
         if pending:
@@ -270,43 +296,67 @@ class NGPTrainer(Trainer):
         if shard:
             # Adam on the owned 1/W of every level group (sums received by the reduce-scatter), then every rank gets the others'
             # updated entries; the accumulator was consumed by the collectives: clear it (one 134 MB memset, ~30 us)
-            params = self.field.table.params
+            params = self._field.table.params
             spans = []
-            for (lo, hi), buf in zip(self.field.level_groups, self._rs_bufs):
+            for (lo, hi), buf in zip(self._field.level_groups, self._rs_bufs):
                 n = buf.numel()
                 spans.append((lo * per_level + self.rank * n, lo * per_level + (self.rank + 1) * n, buf))
-            self._opt.update_spans(self.field.table, spans, grad_scale=1.0 / self.world)
+            self._opt.update_spans(self._field.table, spans, grad_scale=1.0 / self.world)
+            self._moments_synced = False
             flat.zero_()
-            for (lo, hi), (a, b, _) in zip(self.field.level_groups, spans):
-                torch.distributed.all_gather_into_tensor(params[lo * per_level:hi * per_level], params[a:b].clone())
+            # all-gathers of the updated shards on the comm stream, one per level group, behind the Adam launches; the next
+            # step's forward (the first reader of the tables) joins that stream
+            half = self._field.table.half
+            ev = torch.cuda.Event()
+            ev.record()
+            self._comm.wait_event(ev)
+            with torch.cuda.stream(self._comm):
+                for (lo, hi), (a, b, _) in zip(self._field.level_groups, spans):
+                    torch.distributed.all_gather_into_tensor(params[lo * per_level:hi * per_level], params[a:b].clone())
+                    if half is not None:     # the fp16 shadow shards Adam wrote in the same pass travel too: no re-conversion
+                        torch.distributed.all_gather_into_tensor(half[lo * per_level:hi * per_level], half[a:b].clone())
+            if half is not None:
+                self._field.table.mark_updated(shadow_written=True)
         else:
-            self._opt.update(self.field.table, g_tab.view(-1), grad_scale=1.0 / self.world, zero_grads=True)    # reads g, writes 0
-        self.field._grad_clean = True
+            self._opt.update(self._field.table, g_tab.view(-1), grad_scale=1.0 / self.world, zero_grads=True)    # reads g, writes 0
+        self._field._grad_clean = True
         self.it += 1
         return {"loss_coarse": loss}
 
     def render_rays(self, rays: torch.Tensor, u=None):
         outs = []
+        self._join_comm()
         for s in range(0, rays.shape[0], self.chunk):
             r = rays[s:s + self.chunk]
             z = sampling.sample_coarse(r, self.n)
-            raw = self.field.query(r, z)
+            raw = self._field.query(r, z)
             outs.append(render.composite(raw, z, r, 0.0, self.white_bkgd, need_weights=False)[0])
         return torch.cat(outs, 0)
 
-    def state_dict(self):
-        """With sharded table updates (table_sync "shard", world_size > 1) a rank's Adam moments are current on its own
-        shards only: they are gathered here first -- a COLLECTIVE, every rank must call state_dict() / save() together."""
-        if self.world > 1 and self.table_sync == "shard" and "tables" in self._opt.state:
-            per_level = self.field.enc.hash_table_size * self.field.enc.n_features_per_level
+    def sync_optimizer_state(self):
+        """COLLECTIVE (every rank, same iteration): with sharded table updates (table_sync "shard", world_size > 1) a rank's
+        Adam moments are current on its own shards only; this gathers the others'.  A no-op otherwise.  Call it on all ranks
+        before a rank-0 `state_dict()` / `save()` (entrypoints/test_nerf.py does)."""
+        if self.world > 1 and self.table_sync == "shard" and "tables" in self._opt.state and not self._moments_synced:
+            self._join_comm()
+            per_level = self._field.enc.hash_table_size * self._field.enc.n_features_per_level
             for t in self._opt.state["tables"]:
-                for lo, hi in self.field.level_groups:
+                for lo, hi in self._field.level_groups:
                     n = (hi - lo) * per_level // self.world
                     a = lo * per_level + self.rank * n
                     torch.distributed.all_gather_into_tensor(t[lo * per_level:hi * per_level], t[a:a + n].clone())
+        self._moments_synced = True
+
+    def state_dict(self):
+        """Never communicates.  With sharded table updates the Adam moments of the other ranks' shards are stale after a
+        training step: raises until `sync_optimizer_state()` has run (on every rank) at this iteration."""
+        if self.world > 1 and self.table_sync == "shard" and not self._moments_synced:
+            raise RuntimeError("NGPTrainer.state_dict / save: the Adam moments of the hash tables are sharded across ranks "
+                               "(table_sync='shard'); call tr.sync_optimizer_state() on EVERY rank first (a collective), then "
+                               "save from rank 0")
         return super().state_dict()
 
     def _checkpoint_buffers(self):
         """Trainer.save / load / state_dict / load_state_dict work on these: the 2 x 64 MLP and the hash tables, with
         their two Adam (m, v) pairs and step counts (bias correction is on here, so the counts matter)."""
-        return {"mlp": self.field.mlp, "tables": self.field.table}
+        return {"mlp": self._field.mlp, "tables": self._field.table}

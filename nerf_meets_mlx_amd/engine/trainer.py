@@ -37,7 +37,7 @@ class Trainer:
     def __init__(self, images: torch.Tensor, poses: torch.Tensor, K, near: float = 2.0, far: float = 6.0,
                  N_rand: int = 1024, n_depth_samples: int = 64, N_importance: int = 128, lrate: float = 5e-4,
                  lrate_decay: int = 500, white_bkgd: bool = True, ref_quirks: bool = True, seed: int = 0,
-                 device="cuda", chunk: int = 1024 * 32, precision: int = 16, overlap_comm: bool = True):
+                 device="cuda", chunk: int = 1024 * 32, precision: int = 22, overlap_comm: bool = True):
         self.device = torch.device(device)
         self.images = images.to(self.device, torch.float32).contiguous()      # [N,H,W,3], white-composited
         self.poses = poses.float().cpu()
@@ -188,6 +188,12 @@ class Trainer:
         if self.fine is not None:
             b["fine"] = self.fine
         return b
+
+    def sync_optimizer_state(self):
+        """COLLECTIVE hook (every rank, same iteration) that makes this rank's optimiser state complete before a rank-0
+        `state_dict()` / `save()`.  Replicated Adam (this class): nothing to do.  NGPTrainer with sharded table updates
+        gathers the other ranks' moments here."""
+        self._join_comm()
 
     def state_dict(self):
         """Everything a bit-identical continuation needs: iteration, flat parameters, Adam (m, v) + step counts per

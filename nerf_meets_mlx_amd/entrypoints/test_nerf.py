@@ -71,9 +71,11 @@ def main(path_dataset: Optional[str] = None, max_iter: int = 5000, device="cuda"
     losses, frames, saved = [], [], []
     for i in range(tr.it + 1, max_iter + 1):
         out = tr.train_step()
-        if args.i_weights and i % args.i_weights == 0 and tr.rank == 0:
-            os.makedirs(ckpt_dir, exist_ok=True)
-            saved.append(tr.save(os.path.join(ckpt_dir, f"{i:06d}.npz")))
+        if args.i_weights and i % args.i_weights == 0:
+            tr.sync_optimizer_state()        # collective (a no-op for replicated Adam): every rank, then rank 0 writes
+            if tr.rank == 0:
+                os.makedirs(ckpt_dir, exist_ok=True)
+                saved.append(tr.save(os.path.join(ckpt_dir, f"{i:06d}.npz")))
         if i % log_every == 0 or i == max_iter:
             losses.append((i, float(out["loss_coarse"]), float(out.get("loss_fine", torch.zeros(1)))))
         if render_every and i % render_every == 0:

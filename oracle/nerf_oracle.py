@@ -711,12 +711,13 @@ class OracleImageFitter:
         self.m, self.v = torch.zeros_like(self.p), torch.zeros_like(self.p)
         self.lr, self.emu = lr, emulate_bf16
 
-    def forward(self, X):
+    def forward(self, X, masks=None, taps=None):
         x = sinusoidal_encoding(X, 10, 0.0, 8.0, False)
-        return nerf_forward(self.arch, unflatten_params(self.arch, self.p), x, self.emu)
+        return nerf_forward(self.arch, unflatten_params(self.arch, self.p), x, self.emu, masks=masks, taps=taps)
 
-    def step(self, X, y):
-        loss = mse(self.forward(X), y)
+    def step(self, X, y, masks=None):
+        """masks (tests): the ReLU decisions of another implementation of the same forward (see nerf_forward)."""
+        loss = mse(self.forward(X, masks=masks), y)
         g, = torch.autograd.grad(loss, self.p)
         with torch.no_grad():
             adam_step(self.p, g, self.m, self.v, self.lr, b1=0.9, b2=0.99)
@@ -750,7 +751,7 @@ class OracleNGP:
         self.mt = [torch.zeros_like(self.tables), torch.zeros_like(self.tables)]
         self.it = 0
 
-    def render(self, rays):
+    def render(self, rays, masks=None, taps=None):
         o, d, near, far, viewdirs = decompose_ray_batch(rays)
         z = sample_z_uniform(near, far, self.n)
         pts = o[..., None, :] + d[..., None, :] * z[..., :, None]
@@ -758,13 +759,16 @@ class OracleNGP:
         feat = hashgrid_encoding(pts.reshape(-1, 3) * self.pos_scale + self.pos_offset, self.tables, self.res).reshape(B, n, -1)
         shf = sh_encoding(viewdirs, 3)
         x = torch.cat([feat, shf[:, None, :].expand(B, n, shf.shape[-1])], -1).reshape(B * n, -1)
-        raw = nerf_forward(self.arch, unflatten_params(self.arch, self.p), x, self.emu).reshape(B, n, 4)
+        raw = nerf_forward(self.arch, unflatten_params(self.arch, self.p), x, self.emu, masks=masks, taps=taps).reshape(B, n, 4)
+        if taps is not None:
+            taps["raw"], taps["x"] = raw, x
         rgb, *_ = raw2outputs(raw, z, d, 0.0, white_bkgd=self.white)
         return rgb
 
-    def loss_and_grads(self, rays_o, rays_d, target):
+    def loss_and_grads(self, rays_o, rays_d, target, masks=None):
+        """masks (tests): the ReLU decisions of another implementation of the same forward (see nerf_forward)."""
         rays = pack_rays(rays_o, rays_d, self.near, self.far)
-        loss = mse(self.render(rays), target)
+        loss = mse(self.render(rays, masks=masks), target)
         gp, gt = torch.autograd.grad(loss, [self.p, self.tables])
         return loss.detach(), gp, gt
 

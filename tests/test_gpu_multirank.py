@@ -56,8 +56,9 @@ def _worker(rank, world, port, q, tmp):
     overlap_ok = (full._comm is not None and ser._comm is None
                   and torch.equal(full.fine.params, ser.fine.params) and torch.equal(full.coarse.params, ser.coarse.params)
                   and all(torch.equal(a, b) for a, b in zip(full.opt.state["shared"], ser.opt.state["shared"])))
-    # the bench's headline mode under two ranks: same collectives, split-precision kernels -> identical weights on all ranks
-    t22 = Trainer(imgs, poses, K, N_rand=64, n_depth_samples=64, N_importance=128, seed=4, device="cuda", precision=22)
+    # (the trainers above run at the default precision 22.)  The declared bf16 mode under two ranks: same collectives, bf16
+    # kernels -> identical weights on all ranks
+    t22 = Trainer(imgs, poses, K, N_rand=64, n_depth_samples=64, N_importance=128, seed=4, device="cuda", precision=16)
     for _ in range(2):
         t22.train_step()
     p22 = [torch.zeros_like(t22.fine.params) for _ in range(world)]
@@ -104,7 +105,7 @@ def test_two_ranks_keep_identical_weights(tmp_path):
         assert loss == loss
 
 
-def _ngp_worker(rank, world, port, q):
+def _ngp_worker(rank, world, port, q, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
     from nerf_meets_mlx_amd import parallel
@@ -114,10 +115,11 @@ def _ngp_worker(rank, world, port, q):
     parallel.init_from_env(backend="gloo")
     imgs, poses, _, _, K = synthetic.make_dataset(16, 16, 3, seed=0, device="cuda")
     res, finals = [], {}
-    for det, sync in ((True, "shard"), (True, "allreduce"), (False, "shard"), (False, "allreduce")):
+    # precision 22 = the default (float32 gathers, no fp16 shadow); 16 = the bf16 mode with the shadow image
+    for det, sync, prec in ((True, "shard", 22), (True, "allreduce", 22), (False, "shard", 16), (False, "allreduce", 16), (True, "shard", 16)):
         tr = NGPTrainer(imgs, poses, K, N_rand=64, n_depth_samples=64, seed=7, device="cuda", log2_hashmap_size=12,
-                        deterministic=det, level_groups=4, table_sync=sync)
-        assert tr.table_sync == sync
+                        deterministic=det, level_groups=4, table_sync=sync, precision=prec)
+        assert tr.table_sync == sync and (tr.field.table.half is None) == (prec == 22)
         t0 = tr.field.enc.tables.clone()
         for _ in range(3):
             out = tr.train_step()
@@ -130,32 +132,45 @@ def _ngp_worker(rank, world, port, q):
         moved = not torch.equal(t0, tr.field.enc.tables)
         cleared = float(tr.field.enc.grad.abs().max()) == 0.0
         # the fp16 shadow the next query gathers from follows the gathered master tables
-        shadow_ok = torch.equal(tr.field.table.shadow(), tr.field.enc.tables.view(-1).half())
-        # state_dict() is a collective in shard mode: afterwards every rank holds the same, complete Adam moments
+        shadow_ok = prec == 22 or torch.equal(tr.field.table.shadow(), tr.field.enc.tables.view(-1).half())
+        # sharded Adam moments: state_dict() / save() never communicate -- while the moments are stale they RAISE (the
+        # "if rank == 0: save()" idiom of entrypoints/test_nerf.py cannot hang in a collective the other ranks never enter);
+        # sync_optimizer_state() is the explicit collective, after which rank 0 alone can save (advisor, round 4)
+        if sync == "shard":
+            try:
+                tr.state_dict()
+                raised = False
+            except RuntimeError as e:
+                raised = "sync_optimizer_state" in str(e)
+            shadow_ok = shadow_ok and raised
+        tr.sync_optimizer_state()
+        if rank == 0:
+            tr.save(os.path.join(tmp, f"ngp_{int(det)}_{sync}_{prec}.npz"))
         sd = tr.state_dict()
         mv = sd["adam"]["state"]["tables"][0].to("cuda")
         mvs = [torch.zeros_like(mv) for _ in range(world)]
         dist.all_gather(mvs, mv)
         same = same and all(torch.equal(mvs[0], t) for t in mvs) and float(mv.abs().max()) > 0
-        finals[(det, sync)] = (tr.field.enc.tables.clone(), mv)
+        finals[(det, sync, prec)] = (tr.field.enc.tables.clone(), mv)
         res.append((det, same and shadow_ok, moved, cleared, float(out["loss_coarse"])))
     # exact integer sums: the sharded schedule lands on the all-reduce schedule's tables and moments bit for bit
-    eq = torch.equal(finals[(True, "shard")][0], finals[(True, "allreduce")][0]) and torch.equal(finals[(True, "shard")][1], finals[(True, "allreduce")][1])
+    eq = torch.equal(finals[(True, "shard", 22)][0], finals[(True, "allreduce", 22)][0]) and torch.equal(finals[(True, "shard", 22)][1], finals[(True, "allreduce", 22)][1])
     res.append((True, eq, True, True, 0.0))
     q.put((rank, res))
     dist.destroy_process_group()
 
 
-def test_ngp_two_ranks_grouped_table_allreduce_keeps_tables_identical():
+def test_ngp_two_ranks_grouped_table_allreduce_keeps_tables_identical(tmp_path):
     """configs[4] with world_size 2: the table gradient (float32, or int64 fixed point in deterministic mode) is combined level
     group by level group on the comm stream while the next group's scatter and the MLP step run -- by reduce-scatter + Adam on
     the owned shards + all-gather of the updated tables (`table_sync="shard"`, the default) or by all-reduce; after every step
-    both ranks hold bit-identical tables and MLP weights, the accumulators are cleared, the fp16 shadow follows, state_dict()
-    gathers the sharded Adam moments, and in deterministic mode the two schedules give the same tables and moments bit for bit."""
+    both ranks hold bit-identical tables and MLP weights, the accumulators are cleared, the fp16 shadow (precision 16) follows,
+    state_dict() of stale sharded moments raises instead of hanging, sync_optimizer_state() gathers them and rank 0 alone saves,
+    and in deterministic mode the two schedules give the same tables and moments bit for bit."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ngp_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ngp_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=280) for _ in range(world)]

@@ -303,7 +303,7 @@ def test_ngp_half_shadow_tables_follow_the_float32_master():
     interpolated features to bf16 = 2^-9 anyway); (3) master tables and MLP of a run with and without the shadow stay
     within the tolerance the bf16 arithmetic of the step allows."""
     from nerf_meets_mlx_amd import sampling
-    a, b = _ngp(True, half_tables=True), _ngp(True, half_tables=False)
+    a, b = _ngp(True, half_tables=True, precision=16), _ngp(True, half_tables=False, precision=16)      # an option of the bf16 mode
     assert a.field.table.half is not None and b.field.table.half is None
     rays, target = a.sample_batch()
     z = sampling.sample_coarse(rays, 64)

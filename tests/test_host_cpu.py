@@ -45,7 +45,7 @@ def test_host_argument_validation_without_gpu():
     arch32 = _native.MlpArch(8, 256, 63, 27, 4, 1, 4, 32)               # ABI 3: precision is a field of the arch
     assert lib.nerf_mlp_param_count(C.byref(arch)) == 595844 == lib.nerf_mlp_param_count(C.byref(arch32))
     bf16_image = (1184 + 1120) * 1024 + 2496 * 4 + 1184 * 1024          # fwd + bwd streams, biases, 16x16x32 stream
-    fp32_image = (580 + 544) * 4096 + 3136 * 4                           # fp32 reference-precision streams + tail
+    fp32_image = (580 + 544) * 4096 + 3584 * 4                           # fp32 reference-precision streams + tail (round 5: + the image model's 4 x 256 output head)
     assert lib.nerf_mlp_packed_bytes(C.byref(arch)) == bf16_image
     assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 63, 27, 4, 1, 4, 0))) == bf16_image     # 0 = default = 16
     assert lib.nerf_mlp_packed_bytes(C.byref(arch32)) == bf16_image + fp32_image
@@ -66,7 +66,19 @@ def test_host_argument_validation_without_gpu():
     bad = _native.MlpArch(8, 128, 63, 27, 4, 1, 4, 16)
     assert lib.nerf_mlp_param_count(C.byref(bad)) == -1
     assert lib.nerf_mlp_param_count(C.byref(_native.MlpArch(8, 256, 63, 27, 4, 1, 4, 24))) == -1       # unknown precision
-    assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 40, 0, 4, 0, 3, 32))) == -1        # fp32: view model only
+    # round 5: the image-fitting and the 2 x 64 models have reference-tolerance kernels too (split bf16; image: fp32 MFMA as well)
+    img_bf16 = (960 + 928) * 1024 + 2080 * 4
+    assert lib.nerf_mlp_packed_bytes(C.byref(img)) == img_bf16
+    assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 40, 0, 4, 0, 3, 22))) == img_bf16 + (1920 + 1856) * 1024
+    assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(8, 256, 40, 0, 4, 0, 3, 32))) == img_bf16 + fp32_image
+    assert lib.nerf_mlp_acts_bytes(C.byref(_native.MlpArch(8, 256, 40, 0, 4, 0, 3, 22)), 65) == 8 * 270 * 1024
+    assert lib.nerf_mlp_acts_bytes(C.byref(_native.MlpArch(8, 256, 40, 0, 4, 0, 3, 32)), 65) == 3 * 2592 * 128
+    ngp = _native.MlpArch(2, 64, 32, 16, -1, 1, 4, 16)
+    ngp22 = _native.MlpArch(2, 64, 32, 16, -1, 1, 4, 22)
+    assert lib.nerf_mlp_param_count(C.byref(ngp22)) == 13188
+    assert lib.nerf_mlp_packed_bytes(C.byref(ngp22)) == lib.nerf_mlp_packed_bytes(C.byref(ngp)) + 128 * 1024
+    assert lib.nerf_mlp_acts_bytes(C.byref(ngp22), 65) == 8 * 37 * 1024 and lib.nerf_mlp_dz_bytes(C.byref(ngp22), 65) == 8 * 32 * 1024 + 512 * (64 * 1024 + 256) * 4
+    assert lib.nerf_mlp_packed_bytes(C.byref(_native.MlpArch(2, 64, 32, 16, -1, 1, 4, 32))) == -1      # fp32 MFMA: the 8 x 256 models only
     with pytest.raises(ValueError):
         _native.ptr(torch.zeros(3))                                          # CPU tensors are refused: no fallback
 
