@@ -155,6 +155,15 @@ def test_small_model_gradients_and_input_grads_vs_fp32_oracle():
     print(f"[2x64 p22] forward {_relmax(out, want):.1e}; worst dW/db rel-L2 {worst[0]:.1e} at {worst[1]}; d_x {_rel_l2(d_x, xr.grad[:, :32]):.1e}")
 
 
+def _make_alive(tr, orc):
+    """The seed-0 2 x 64 network is DEAD at initialisation under the reference's un-activated sigma (sigma in [-0.22, -0.10] on
+    every sample -> all compositing weights 0, rgb = white, every gradient exactly 0: DESIGN.md section 7): a gradient comparison
+    on it is 0 == 0.  Lift the alpha bias (flat index 10496 = LN::P_BA) on both sides."""
+    with torch.no_grad():
+        orc.p[10496] += 0.6
+    tr.field.mlp.load_flat(orc.p.detach())
+
+
 def test_image_fitter_default_tracks_the_float32_oracle_loop():
     """entrypoints/__viser_image_learning.py:198-236 headless at the DEFAULT precision against the float32 oracle loop: first
     loss to 1e-3 (measured ~1e-6), mask-aligned gradient of the first batch <= 1e-3 rel-L2, losses of six Adam steps within
@@ -176,6 +185,7 @@ def test_image_fitter_default_tracks_the_float32_oracle_loop():
     g = fit.model.backward(d_pred).cpu().clone()
     masks = {f"pos{l}": debug_layer(fit.model, "acts", l).cpu() > 0 for l in range(8)}
     want_loss = O.mse(orc.forward(X.cpu()), y.cpu())
+    want_loss = want_loss.detach()
     assert abs(float(loss) - float(want_loss)) < 1e-3 * float(want_loss), (float(loss), float(want_loss))
     gw, = torch.autograd.grad(O.mse(orc.forward(X.cpu(), masks=masks), y.cpu()), orc.p)
     assert _rel_l2(g, gw) < 1e-3, _rel_l2(g, gw)
@@ -208,6 +218,7 @@ def test_ngp_default_field_gradients_and_training_track_the_float32_oracle():
     assert tr.field.precision == 22 and tr.field.mlp.precision == 22 and tr.field.table.half is None
     orc = O.OracleNGP(tr.field.enc.tables.cpu(), tr.field.enc.scaled_res, seed=0, n_samples=32)
     assert torch.equal(tr.field.mlp.params.cpu(), orc.p.detach())
+    _make_alive(tr, orc)
     rays, target = tr.sample_batch()
     ro, rd, tg = rays[:, 0:3].cpu(), rays[:, 3:6].cpu(), target.cpu()
     z = sampling.sample_coarse(rays, 32)
@@ -226,6 +237,7 @@ def test_ngp_default_field_gradients_and_training_track_the_float32_oracle():
     masks = {n: debug_layer(tr.field.mlp, "acts", l).cpu() > 0 for n, l in (("pos0", 0), ("pos1", 1), ("dir0", 9))}
     lo, gp, gt = orc.loss_and_grads(ro, rd, tg, masks=masks)
     assert abs(float(loss) - float(lo)) < 1e-3 * float(lo), (float(loss), float(lo))
+    assert float(gp.norm()) > 1e-3 and float(gt.norm()) > 1e-4, "dead network: the comparison would be 0 == 0"
     assert _rel_l2(g_mlp, gp) < 1e-3, _rel_l2(g_mlp, gp)
     assert _rel_l2(g_tab, gt) < 1e-3, _rel_l2(g_tab, gt)
     hip, ora = [], []
