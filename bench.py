@@ -44,8 +44,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix (v_
 TRAIN_BYTES = {16: (321 + 356 + 9) * 1024 / 32, 22: (633 + 712 + 9 + 12) * 1024 / 32, 32: (2592 + 2496) * 128 * 2 / 32}
 PEAK_TFLOPS = {16: BF16_MFMA_PEAK_TFLOPS, 22: BF16_MFMA_PEAK_TFLOPS / 3.0, 32: FP32_MFMA_PEAK_TFLOPS}
 KERNEL = {16: "mlp_fwd_ring16_kernel<8,2>", 22: "mlp22_fwd_kernel<1>", 32: "mlp32_fwd_kernel"}
-DTYPE = {16: "bf16", 22: "f32 (split 16-bit MFMA operands: fp16 hi+lo render, bf16 hi+lo training; fp32 accumulate)", 32: "f32"}
-DTYPE_SHORT = {16: "bf16", 22: "f32_split16", 32: "f32"}
+# what the MFMA OPERANDS are (the label says operands, not the tolerance met): precision 22 carries every float32 GEMM operand as
+# two 16-bit numbers -- fp16 x 2 in rendering (22 significand bits), bf16 x 2 in training (16 significand bits) -- and accumulates
+# in fp32; it is held to the float32 kernels' fixture tolerances (1e-4 of the output scale), but its operands are NOT float32
+DTYPE = {16: "bf16", 22: "split16 (fp16x2 render / bf16x2 train MFMA operands ~ 22 / 16 significand bits; fp32 accumulate)", 32: "f32"}
+DTYPE_SHORT = {16: "bf16", 22: "split16", 32: "f32"}
+OPERAND_BITS = {16: {"render": 8, "train": 8}, 22: {"render": 22, "train": 16}, 32: {"render": 24, "train": 24}}
+NGP_DTYPE = {16: "bf16 (MLP operands; fp16 shadow-table gathers, float32 interpolation rounded to bf16)",
+             22: "split16 (bf16x2 MLP operands ~ 16 significand bits, fp32 accumulate; float32 table gathers and interpolation)"}
 
 
 def main():
@@ -165,9 +171,14 @@ def main():
             out, rgb = step()
         barrier()
         dt = time.perf_counter() - t0
-        comm_ms = None
+        comm_ms, rank_ms = None, None
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            # every rank's own wall time of the timed region, next to the MAX the contract asks for: the first SCALE record can
+            # then separate rank skew (min vs max) from collective time (comm_ms_per_step)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(every, t)
+            rank_ms = [float(x[0]) / steps * 1e3 for x in every]
             cm = parallel.comm_timing
             parallel.comm_timing = None                          # the two reductions below are not part of the step
             # collective time per step on this rank (events on the stream the collectives are issued on; includes waiting
@@ -182,7 +193,8 @@ def main():
         return {"dt": dt, "steps": steps, "value": (n_rand + args.render_rays) * world * steps / dt, "n_rand": n_rand,
                 "ms_per_step": dt / steps * 1e3, "k_ms": float(np.mean([a.elapsed_time(b) for a, b in ev])),
                 "t_train": t_train, "t_render": t_render, "loss_coarse": float(out["loss_coarse"]),
-                "loss_fine": float(out.get("loss_fine", torch.zeros(1))), "comm_ms_per_step": comm_ms, "trainer": tr}
+                "loss_fine": float(out.get("loss_fine", torch.zeros(1))), "comm_ms_per_step": comm_ms, "rank_ms_per_step": rank_ms,
+                "trainer": tr}
 
     def frame_leg(tr):
         """ONE full frame through the PUBLIC API, `render.render(H, W, K, chunk=32768, c2w=...)` (rendering/render.py:268-345 of
@@ -269,13 +281,16 @@ def main():
         "metric": f"train+render rays/sec on Lego {H}x{W} (synthetic), " + (f"coarse+fine 64+{NI}" if NI > 0 else "coarse-only 64"),
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": DTYPE[HP], "data": "synthetic",
+        "dtype": DTYPE[HP], "operand_significand_bits": OPERAND_BITS[HP], "data": "synthetic",
         "config": {"workload": (f"configs[2]: Lego {H}x{W} coarse+fine NeRF (64+{NI} importance samples), " if NI > 0 else
                                 f"configs[1]: Lego {H}x{W} coarse-only NeRF (64 samples/ray), ")
                                + f"step = train N_rand={args.n_rand} rays + render chunk {args.render_rays} rays per GPU; " + mode_text,
                    "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}",
                    "precision": HP},
         "comm_ms_per_step": m["comm_ms_per_step"],
+        # per-rank wall time per step of the timed region (ms_per_step above is their MAX); null at N = 1
+        "rank_ms_per_step": (None if m["rank_ms_per_step"] is None else
+                             {"min": min(m["rank_ms_per_step"]), "max": max(m["rank_ms_per_step"]), "ranks": m["rank_ms_per_step"]}),
         "train_rays_per_s_per_gpu": hd["train_rays_per_s"], "render_rays_per_s_per_gpu": hd["render_rays_per_s"],
         "train_mfma_frac": hd["train_mfma_frac"], "render_mfma_frac": hd["render_mfma_frac"],
         # the training phase against its other roofline: activations + dZ written once and read once by the weight-gradient
@@ -328,9 +343,10 @@ def main():
         line["frame"] = {DTYPE_SHORT[p_]: frame_leg(trainers[p_]) for p_ in (22, 16, 32) if p_ in trainers}
         trainers.clear()
         # ---- ngp: BASELINE configs[4] (hash grid + 2x64 MLP), its own step and roofline (the table-gradient scatter)
-        ngp_line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev)
+        # value = the reference-tolerance mode (precision 22); the declared reduced-precision bf16 mode rides along as `bf16`
+        ngp_line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev, extra_bf16=True)
         line["ngp"] = {k: ngp_line[k] for k in ("value", "unit", "ms_per_step", "steps", "train_rays_per_s_per_gpu",
-                                                "render_rays_per_s_per_gpu", "roofline", "dtype", "loss_coarse")}
+                                                "render_rays_per_s_per_gpu", "roofline", "dtype", "loss_coarse", "bf16") if k in ngp_line}
         line["ngp"]["workload"] = ngp_line["config"]["workload"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
@@ -389,7 +405,7 @@ def _latest_profile(pattern):
 
 
 def bench_ngp(args, imgs, poses, rposes, K, rank, world, dev):
-    line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev)
+    line = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev, extra_bf16=(world == 1 and not args.no_extra_legs))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_ngp(args)
     if rank == 0:
@@ -398,15 +414,20 @@ def bench_ngp(args, imgs, poses, rposes, K, rank, world, dev):
         torch.distributed.destroy_process_group()
 
 
-def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev):
+def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev, precision=None, extra_bf16=False):
     """BASELINE configs[4]: hash grid (16 levels x 2^19 x 2) + SH + NeRF 2x64, 64 samples per ray, coarse-only loop.
     Same step structure as the headline bench (train N_rand rays + render one chunk); the dominant kernel is the
-    hash-grid gradient scatter (float atomics), reported against the HBM roofline with its algorithmic bytes."""
+    hash-grid gradient scatter (float atomics), reported against the HBM roofline with its algorithmic bytes.
+    precision: of the 2 x 64 network and its inputs (default: --precision when it is 16 or 22, else 22 -- the reference
+    tolerance: float32 gathers + interpolation, split-bf16 MLP); extra_bf16: also measure the declared bf16 mode as `bf16`."""
     from nerf_meets_mlx_amd import parallel
     from nerf_meets_mlx_amd.engine.ngp import NGPTrainer
     from nerf_meets_mlx_amd.rendering import ray
     H = W = args.hw
-    tr = NGPTrainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, seed=4, device=dev, chunk=args.render_rays)
+    if precision is None:
+        precision = args.precision if args.precision in (16, 22) else 22
+    tr = NGPTrainer(imgs, poses, K, N_rand=args.n_rand, n_depth_samples=64, seed=4, device=dev, chunk=args.render_rays,
+                    precision=precision)
     tr.field.timing = []
     lo, _ = parallel.shard_range(H * W, rank, world)
     lo = min(lo, H * W - args.render_rays)
@@ -432,8 +453,12 @@ def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev):
         out, rgb = step()
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        rank_ms = [float(x[0]) / args.steps * 1e3 for x in every]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t[0])
     assert torch.isfinite(rgb).all() and torch.isfinite(out["loss_coarse"]).all()
@@ -446,10 +471,14 @@ def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev):
         "metric": f"train+render rays/sec on Lego {H}x{W} (synthetic), hash grid 16x2^19x2 + SH3 + 2x64 MLP, 64 samples/ray",
         "value": (args.n_rand + args.render_rays) * world * args.steps / dt, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": NGP_DTYPE[precision],
+        "operand_significand_bits": {"render": 16 if precision == 22 else 8, "train": 16 if precision == 22 else 8}, "data": "synthetic",
         "config": {"workload": f"configs[4]: Lego {H}x{W} hash-grid + tiny fused MLP, step = train N_rand={args.n_rand} rays + render "
-                               f"chunk {args.render_rays} rays per GPU, 64 samples per ray", "n_rand_per_gpu": args.n_rand,
-                   "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}"},
+                               f"chunk {args.render_rays} rays per GPU, 64 samples per ray; precision {precision}"
+                               + (" (the reference's float32 tolerance)" if precision == 22 else " (declared reduced precision)"),
+                   "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}",
+                   "precision": precision},
+        "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms},
         "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
         "loss_coarse": float(out["loss_coarse"]),
         "roofline": {"bound": "hbm", "kernel": "hashgrid_bwd_combine_kernel<2> (levels 0-4) + hashgrid_bwd_kernel<2, 4> (table gradient scatter, "
@@ -461,6 +490,13 @@ def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev):
                              "8-byte integer atomics cost what 4-byte float atomics cost); algorithmic bytes count a read-modify-write of 256 float32 "
                              "table entries per sample"},
     }
+    if extra_bf16 and precision != 16:
+        del tr
+        torch.cuda.empty_cache()
+        b = measure_ngp(args, imgs, poses, rposes, K, rank, world, dev, precision=16)
+        line["bf16"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "steps", "train_rays_per_s_per_gpu", "render_rays_per_s_per_gpu",
+                                          "dtype", "loss_coarse")}
+        line["bf16"]["scatter_ms_per_launch"] = b["roofline"]["ms_per_launch"]
     return line
 
 

@@ -914,3 +914,10 @@ def test_bench_prints_one_contract_json_line(extra):
         assert d["sustained"]["seconds"] >= 1.0 and 0.3 < d["sustained"]["ratio_to_burst"] < 3.0
         assert d["fp32"]["dtype"] == "f32" and d["fp32"]["roofline"]["peak"] == 157.3 and d["fp32"]["value"] < d["value"]
         assert d["lego_batch"]["n_rand_per_gpu"] == 1024 and "roofline" in d["ngp"]
+        # round 5: the label names the OPERANDS (two 16-bit numbers per float32 value), and configs[4]'s value is the
+        # reference-tolerance mode with the bf16 mode as a declared extra leg
+        assert not d["dtype"].startswith("f32") and d["operand_significand_bits"] == {"render": 22, "train": 16}
+        assert d["ngp"]["dtype"].startswith("split16") and d["ngp"]["bf16"]["value"] > 0 and d["ngp"]["bf16"]["dtype"].startswith("bf16")
+    if "--config" in extra:
+        assert d["config"]["precision"] == 22 and d["dtype"].startswith("split16") and d["bf16"]["value"] > 0
+    assert d["rank_ms_per_step"] is None                                   # N = 1
