@@ -121,6 +121,10 @@ struct RingW {
   // k = 0..7 and nothing else writes M0 in these kernels (tools/check_m0.py)
   const char* run_base;                // source base of the current run of four (NERF_DMA_CLOBBER_M0, DPW == 8)
   __device__ __forceinline__ void issue_one(int chunk, int stage, int k) {
+#if NERF_ABLATE == 20         // timing-only build 20: every refill is a BARE LDS-DMA (no M0 write, no hazard nop, stale base): the bookkeeping's share
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(lane16), "s"(wsrc) : "memory");
+    return;
+#endif
 #if NERF_DMA_CLOBBER_M0
     if (RUN4 && DPW == 8) {
       const int i = wv * DPW + k;
@@ -131,7 +135,15 @@ struct RingW {
         // ONE asm template with an immediate operand (k is a constant at every call site after unrolling).  A switch over three
         // templated statements compiled to the same DMAs but tipped hipcc's register allocation of the split-bf16 chain kernel
         // into scratch (857 scratch instructions, +3 ms, all tests green): the Makefile scan now fails the build on that.
+#ifdef NERF_RING_SWITCH_DMA      // diagnostic form (a run-time k compiles): three literal statements
+        switch (k & 3) {
+          case 1: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(lane16), "s"(run_base) : "memory"); break;
+          case 2: asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(lane16), "s"(run_base) : "memory"); break;
+          default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(lane16), "s"(run_base) : "memory"); break;
+        }
+#else
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" :: "v"(lane16), "s"(run_base), "i"((k & 3) * 1024) : "memory");
+#endif
       }
       return;
     }
@@ -146,7 +158,9 @@ struct RingW {
   // Whole chunks refill their freed stage one DMA per quarter of the interval (a burst of 4 right behind the barrier
   // stalls both waves of a SIMD on the VMEM issue path at once); the partial last chunk of a pass keeps the burst.
   // (not in the activation-storing training forward, RING_GROUP 2: it is at the VGPR limit and HBM-bound anyway)
-  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && RING_GROUP == 4 && (c + 1) * CHUNK <= TOTAL; }
+  // RING_GROUP 8 (a group = 8 fragments = a quarter chunk: reads issued twice as far ahead of their use): two refill DMAs per group
+  static constexpr int DMA_PER_GROUP = RING_GROUP * DPW / CHUNK;        // 1 (group 4, DPW 8) or 2 (group 8, DPW 8)
+  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && (RING_GROUP == 4 || (RING_GROUP == 8 && DPW == 8)) && (c + 1) * CHUNK <= TOTAL; }
   __device__ __forceinline__ void boundary(int c, int lane) {
     ring_pos = (ring_pos + 1) & (STAGES - 1);
 #if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
@@ -165,8 +179,10 @@ struct RingW {
     }
 #endif
 #if NERF_ABLATE != 2          // timing-only build 2: no refill DMA (stale weights)
-    if (spread(c)) issue_one((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), 0);
-    else issue((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1));
+    if (spread(c)) {
+      issue_one((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), 0);
+      if (RING_GROUP == 8) issue_one((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), 1);
+    } else issue((c + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1));
 #endif
     woff = ring_pos * STAGE_BYTES + 16 * lane;
   }
@@ -175,7 +191,10 @@ struct RingW {
   __device__ __forceinline__ void prefetch(int fn, int lane) {
     if ((fn % CHUNK) == 0) boundary(fn / CHUNK, lane);
 #if NERF_ABLATE != 2
-    else if ((fn % (CHUNK / DPW)) == 0 && spread(fn / CHUNK))
+    else if (RING_GROUP == 8 && spread(fn / CHUNK)) {
+      issue_one((fn / CHUNK + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), (fn % CHUNK) / (CHUNK / DPW));
+      issue_one((fn / CHUNK + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1), (fn % CHUNK) / (CHUNK / DPW) + 1);
+    } else if ((fn % (CHUNK / DPW)) == 0 && spread(fn / CHUNK))
       issue_one((fn / CHUNK + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1),
                 (fn % CHUNK) / (CHUNK / DPW));
 #endif

@@ -91,11 +91,21 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int fp = fbase + nt * KS + ks;
+#if NERF_ABLATE == 11 || NERF_ABLATE == 12      // timing-only builds: no weight fragments from the ring (no LDS reads, no ring protocol)
+      const bf16x8 ah = ih[(ks + 1) % KS], al = il[(ks + 1) % KS];
+      (void)fp;
+#else
       const bf16x8 ah = next_frag(ws, 2 * fp, lane);
       const bf16x8 al = next_frag(ws, 2 * fp + 1, lane);
+#endif
       acc = mfma32(ah, il[ks], acc);
       acc = mfma32(al, ih[ks], acc);
       acc = mfma32(ah, ih[ks], acc);
+#if NERF_ABLATE == 10 || NERF_ABLATE == 12      // timing-only builds: no epilogue (the next layer computes on this layer's inputs)
+      if (ks == 0) { oh[2 * nt] = ih[(2 * nt) % KS]; oh[2 * nt + 1] = ih[(2 * nt + 1) % KS]; ol[2 * nt] = il[(2 * nt) % KS]; ol[2 * nt + 1] = il[(2 * nt + 1) % KS]; }
+      if (ks == KS - 1) asm volatile("" :: "v"(acc));
+      if (false)
+#endif
       if (nt > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -107,6 +117,9 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
     }
     prev = acc;
   }
+#if NERF_ABLATE == 10 || NERF_ABLATE == 12
+  return;
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     finish_quarter<RELU, MASKOUT>(prev, q, NT - 1, oh[2 * NT - 2], oh[2 * NT - 1], ol[2 * NT - 2], ol[2 * NT - 1], mask);

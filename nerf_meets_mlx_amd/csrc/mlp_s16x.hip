@@ -48,7 +48,10 @@ struct DevOnce {
 constexpr int NW = 4;                                    // waves per workgroup: one per SIMD (256 activation registers)
 constexpr int IMG_F_CHUNKS = IMG_F_FRAGS / RING_CHUNK, IMG_B_CHUNKS = IMG_B_PADDED / RING_CHUNK;      // 60, 58
 static_assert(IMG_F_CHUNKS * RING_CHUNK == IMG_F_FRAGS && IMG_B_CHUNKS * RING_CHUNK == IMG_B_PADDED, "whole ring chunks");
-typedef RingW<IMG_F_CHUNKS, IMG_F_FRAGS, 4, NW, RING_CHUNK, RING_STAGES, true> ImgFwdRing;
+#ifndef NERF_S16X_GROUP
+#define NERF_S16X_GROUP 4
+#endif
+typedef RingW<IMG_F_CHUNKS, IMG_F_FRAGS, NERF_S16X_GROUP, NW, RING_CHUNK, RING_STAGES, true> ImgFwdRing;
 typedef RingW<IMG_B_CHUNKS, IMG_B_FRAGS, 4, NW, RING_CHUNK, RING_STAGES, true> ImgBwdRing;
 
 constexpr int IMG_PACK_PAIRS = LI::F_TOTAL + LI::B_PADDED;

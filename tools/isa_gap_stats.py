@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Instruction mix and MFMA-gap budget of a kernel in a -save-temps ISA file (one wave per SIMD: every non-MFMA instruction costs
+an issue slot of ~4 cycles, an MFMA holds the issue port for 8 of its 16 (16x16x32) or 32 (32x32x16) cycles: MI355X_MICROARCH.md,
+row 'vector-instruction ISSUE cost').   python tools/isa_gap_stats.py file.s kernel_substring [--dump N]"""
+import sys
+from collections import Counter
+
+COST = {'VALU': 4, 'DS': 4, 'WAIT': 4, 'SALU': 4, 'NOP': 4, 'ACC': 4, 'TRANS': 8, 'DMA': 16, 'VMEM': 8, 'BARRIER': 4, 'OTHER': 4}
+
+
+def cls(i):
+    op = i.split()[0]
+    if op.startswith('v_mfma'): return 'MFMA'
+    if op.startswith('ds_'): return 'DS'
+    if op.startswith('global_load_lds'): return 'DMA'
+    if op.startswith(('global_', 'buffer_', 'flat_')): return 'VMEM'
+    if op.startswith('s_waitcnt'): return 'WAIT'
+    if op.startswith('s_barrier'): return 'BARRIER'
+    if op.startswith('s_nop'): return 'NOP'
+    if op.startswith('s_'): return 'SALU'
+    if op.startswith('v_accvgpr'): return 'ACC'
+    if op.startswith(('v_sin', 'v_cos', 'v_exp', 'v_rcp', 'v_log', 'v_sqrt', 'v_rsq')): return 'TRANS'
+    if op.startswith('v_'): return 'VALU'
+    return 'OTHER'
+
+
+def kernel_body(text, sub):
+    for line in text.split('\n'):
+        head = line.split(';')[0].rstrip()
+        if head.endswith(':') and sub in head and not line.startswith(('.', '\t')):
+            start = text.index(line)
+            end = text.index('.Lfunc_end', start)
+            return head[:-1], [l.strip() for l in text[start:end].split('\n') if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
+    raise SystemExit(f"no kernel matching {sub}")
+
+
+def main():
+    text = open(sys.argv[1]).read()
+    name, ins = kernel_body(text, sys.argv[2])
+    c = Counter(cls(i) for i in ins)
+    mf = [i for i in ins if cls(i) == 'MFMA']
+    per = 32 if mf and '32x32' in mf[0] else 16
+    gaps, cur, seen = [], 0, False
+    for i in ins:
+        k = cls(i)
+        if k == 'MFMA':
+            if seen: gaps.append(cur)
+            seen, cur = True, 0
+        else:
+            cur += COST[k]
+    free = per - 8
+    tot = sum(gaps)
+    exposed = sum(max(0, g - free) for g in gaps)
+    n = len(gaps) + 1
+    print(name)
+    print("  instructions", len(ins), dict(c))
+    print(f"  MFMA {n} x {per} = {n * per} cycles; filler issue cost {tot}; free slots {n * free}; issue-bound floor {max(n * per, n * 8 + tot)}"
+          f" ({n * per / max(n * per, n * 8 + tot):.3f} busy); as scheduled (no stalls) {n * per + exposed} ({n * per / (n * per + exposed):.3f} busy)")
+    print("  gap histogram (fillers x4 cycles):", sorted(Counter(min(g // 4, 24) for g in gaps).items()))
+    if '--dump' in sys.argv:
+        k = int(sys.argv[sys.argv.index('--dump') + 1])
+        seen = 0
+        for idx, l in enumerate(ins):
+            if cls(l) == 'MFMA':
+                seen += 1
+                if seen == k:
+                    print('\n'.join(ins[idx:idx + 150]))
+                    break
+
+
+if __name__ == "__main__":
+    main()
