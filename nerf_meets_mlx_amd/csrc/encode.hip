@@ -129,12 +129,24 @@ __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(PointSrc ps, int64_t 
   float* d_tables = static_cast<float*>(d_tables_v);
   unsigned long long* d_fixed = static_cast<unsigned long long*>(d_tables_v);
   auto add = [&](size_t idx, float v) {
+#ifdef NERF_SCATTER_PAIR_PROBE
+    if (F == 2 && !FIXED) { atomicAdd(reinterpret_cast<unsigned long long*>(d_tables + idx), (unsigned long long)__float_as_uint(v)); return; }
+#endif
     if (FIXED) atomicAdd(d_fixed + idx, (unsigned long long)nerf_to_fixed(v));
     else atomicAdd(d_tables + idx, v);
   };
+#ifdef NERF_SCATTER_PAIR_PROBE
+  // TIMING-ONLY build (tools/ab_one.sh ... -DNERF_SCATTER_PAIR_PROBE; wrong gradients): ONE 8-byte atomic per (sample, corner) instead
+  // of one per (sample, corner, feature) -- what packing the F = 2 features of a table entry into a single request would buy.
+  // Float mode: a 64-bit integer add on the entry's (f0, f1) pair; fixed mode: feature 0's accumulator only.  Half the lanes idle.
+  const bool pair_probe = F == 2;
+#else
+  const bool pair_probe = false;
+#endif
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = t / (2 * F);
     const int q = (int)(t - m * (2 * F)), f = q % F, dx = q / F;
+    if (pair_probe && f != 0) continue;
     float px, py, pz;
     point_of(ps, m, px, py, pz);
 #pragma unroll
