@@ -48,7 +48,9 @@ __device__ __forceinline__ long long nerf_to_fixed(float v) {
   return __double2ll_rn((double)v * NERF_HASH_FIX_SCALE);
 }
 __device__ __forceinline__ bool nerf_fixed_is_poisoned(long long a) {
-  return (unsigned long long)(a + (1ll << 60)) >= (1ull << 61);        // a outside [-2^60, 2^60)
+  // a outside the OPEN interval (-2^60, 2^60): symmetric, so that a lone negative saturated addend (-2^60 exactly) reads as NaN
+  // like a positive one (round 4 tested [-2^60, 2^60): -256 passed as a finite gradient)
+  return a <= -(1ll << 60) || a >= (1ll << 60);
 }
 
 __device__ __forceinline__ uint32_t hash3(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t mask) {

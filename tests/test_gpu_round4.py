@@ -159,6 +159,33 @@ def test_ngp_deterministic_scatter_surfaces_nonfinite_and_out_of_range_gradients
     assert int(tr.field.enc.grad.abs().max()) == 0        # consumed and cleared all the same
 
 
+def test_ngp_deterministic_scatter_single_negative_saturated_addend_is_nan():
+    """The poisoned window is symmetric (advisor, round 4): ONE addend below -256 on an otherwise untouched entry saturates to
+    -2^60 units exactly and must come back as NaN, like +2^60 does -- not as a finite -256 gradient."""
+    import ctypes as C
+    from nerf_meets_mlx_amd import _native as N
+    L, log2T, F = 2, 8, 2
+    res = (C.c_int * L)(4, 8)
+    x = torch.tensor([[0.3, 0.6, 0.2]], device=DEV)
+    for sign in (-1.0, 1.0):
+        d_out = torch.zeros(1, L * F, device=DEV)
+        d_out[0, 0] = sign * 1e9                              # feature 0 of level 0: every corner weight x 1e9 is far beyond 256
+        acc = torch.zeros(L, 1 << log2T, F, dtype=torch.int64, device=DEV)
+        N.check(N.lib().nerf_hashgrid_backward_ex(N.ptr(x), 1, N.ptr(d_out), L, log2T, F, res, 0, L, 1, N.ptr(acc), N.stream()))
+        touched = acc[0, :, 0] != 0
+        assert 1 <= int(touched.sum()) <= 8
+        assert bool((acc[0, touched, 0] * int(sign) >= (1 << 60)).all())       # saturated (a corner alone on its entry: exactly +-2^60)
+        params = torch.zeros(acc.numel(), device=DEV)
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        N.check(N.lib().nerf_adam_step_ex(N.ptr(params), N.ptr(acc), N.ptr(m), N.ptr(v), params.numel(), 1e-3, 0.9, 0.99, 1e-8, 1, 1, 1.0,
+                                          1, 1, N.stream()))
+        torch.cuda.synchronize()
+        p = params.view(L, 1 << log2T, F)
+        assert bool(torch.isnan(p[0, touched, 0]).all()), sign
+        assert bool(torch.isfinite(p[0, ~touched, 0]).all()) and bool(torch.isfinite(p[1]).all())
+        assert int(acc.abs().max()) == 0
+
+
 # ------------------------------------------------------------------------------------------------ a11 adjoint: split-bf16 training
 @pytest.mark.parametrize("B,n", [(64, 96), (37, 45), (300, 64)])
 def test_split_bf16_training_kernels_vs_fp32_oracle(B, n):

@@ -1,50 +1,13 @@
 #!/usr/bin/env python3
-"""Scan gfx950 ISA for uses of M0 other than the LDS-DMA statements of csrc/mlp_ring.h (`s_mov_b32 m0, <sgpr>` directly in
-front of a `global_load_lds_*`).  The split-precision kernels are built with NERF_DMA_CLOBBER_M0: their asm writes M0 and does
-not restore it, which is valid only while nothing the COMPILER generated reads M0 or expects a value it put there.
-    python tools/check_m0.py build/mlp22-hip-amdgcn-amd-amdhsa-gfx950.s [--kernels substr ...]"""
-import argparse
-import re
-import sys
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("asm")
-    ap.add_argument("--kernels", nargs="*", default=[])
-    ap.add_argument("--no-scratch", action="store_true", help="also fail when a scanned kernel contains scratch (spill) instructions: "
-                    "the one-wave-per-SIMD kernels are sized to the 512-register file; a change that tips hipcc into scratch costs "
-                    "them a factor (round 4: +3 ms on the split-bf16 chain kernel) without failing any test")
-    a = ap.parse_args()
-    text = open(a.asm).read()
-    bad, seen = 0, 0
-    for m in re.finditer(r"^(_Z[^\n:]*):[^\n]*\n", text, re.M):
-        name = m.group(1)
-        if a.kernels and not any(k in name for k in a.kernels):
-            continue
-        end = text.find(".Lfunc_end", m.end())
-        body = [ln.split(";")[0].strip() for ln in text[m.end():end].split("\n")]
-        body = [ln for ln in body if ln and not ln.startswith(".")]
-        seen += 1
-        ours = other = 0
-        for i, ln in enumerate(body):
-            if not re.search(r"\bm0\b", ln):
-                continue
-            nxt = [x for x in body[i + 1:i + 4]]
-            if re.match(r"s_mov_b32 m0, s\d+$", ln) and any(x.startswith("global_load_lds") for x in nxt):
-                ours += 1
-            else:
-                other += 1
-                if other <= 5:
-                    print(f"    {name}: compiler-side M0 use: {ln}")
-        spills = sum(1 for ln in body if ln.startswith("scratch_")) if a.no_scratch else 0
-        print(f"{name}: {ours} LDS-DMA M0 writes, {other} other M0 uses" + (f", {spills} scratch instructions" if a.no_scratch else ""))
-        bad += other + spills
-    if not seen:
-        print("no kernel matched", file=sys.stderr)
-        return 2
-    return 1 if bad else 0
-
-
+"""Shim: the scanner lives next to the Makefile that runs it (nerf_meets_mlx_amd/csrc/check_m0.py), so that the library builds
+from the package directory alone."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerf_meets_mlx_amd", "csrc"))
+if "check_m0" in sys.modules and sys.modules["check_m0"].__file__ == __file__:
+    del sys.modules["check_m0"]
+import importlib.util
+_spec = importlib.util.spec_from_file_location("_csrc_check_m0", os.path.join(sys.path[0], "check_m0.py"))
+_mod = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_mod)
+main = _mod.main
 if __name__ == "__main__":
     sys.exit(main())

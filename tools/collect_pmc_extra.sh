@@ -2,7 +2,7 @@
 # Extra PMC passes (own runs, counters only): matrix-pipe busy cycles + GPU active cycles, LDS conflicts.
 set -e
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 cd $GRAFT_REPO_ROOT

@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): bench line, rocprofv3 kernel stats, the two PMC passes.  Raw output under gpurun_out/.
 set -e
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
