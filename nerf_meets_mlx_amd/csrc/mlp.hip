@@ -1571,7 +1571,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "dw_job_mask")) { g_dw_job_mask = value; return NERF_OK; }
   if (!strcmp(key, "hash_combine_max_res")) { g_hash_combine_max_res = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "ngp_ray_major")) { g_ngp_ray_major = value ? 1 : 0; return NERF_OK; }
-  if (!strcmp(key, "dw22_variant")) { s16::g_dw_variant = value ? 1 : 0; return NERF_OK; }
+  if (!strcmp(key, "dw22_variant")) { s16::g_dw_variant = (value >= 0 && value <= 2) ? value : 1; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 

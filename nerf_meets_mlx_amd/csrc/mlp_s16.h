@@ -33,7 +33,7 @@ int backward_chain(const void* packed_s16, const void* acts, const float* d_raw,
                    int64_t zstride16, int persistent_wgs, hipStream_t s);
 // the weight-gradient kernel proper (job table, split and partial slots prepared by mlp.hip's launch_dw)
 int launch_dw_kernel(const DwArgs& d, int workgroups, hipStream_t s);
-extern int g_dw_variant;      // A/B knob ("dw22_variant"): 1 = software-pipelined 8-wave kernel (default), 0 = the 16-wave kernel of round 4
+extern int g_dw_variant;      // A/B knob ("dw22_variant"): 2 = 16 waves, one barrier per sample tile (default); 1 = 8 waves, two operand sets; 0 = round 4's form
 
 }  // namespace s16
 }  // namespace nerf

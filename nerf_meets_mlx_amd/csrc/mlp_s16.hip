@@ -327,6 +327,14 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
   return cvt.v;
 }
 
+// PAIR ("dw22_variant" 2, round 5): one barrier per TWO stages (a whole 32-sample tile): the pair is waited for, the barrier
+// frees the previous pair's slots, the next pair is issued into them (64 KiB in flight while 64 KiB are processed), then both
+// half tiles are processed back to back -- the fixed cost of a stage boundary (barrier skew, the refill DMAs' blocked issue, the
+// LDS latency in front of the first MFMA) is paid once per 24 MFMAs of a wave instead of once per 12.  Measured (tools/probe_dw22.py,
+// 786 k samples): 3.42-3.46 ms against 3.72-3.78 (-8 %), gradients bit-identical; the default since round 5.  (The kernel arguments
+// the loop needs are copied into SGPRs in front of it: with the stage body a lambda, hipcc re-loaded them inside the loop, and a
+// scalar load there makes it wait with lgkmcnt(0) in front of every MFMA group: 4.07 ms.)
+template <bool PAIR>
 __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   char* smem = ring_smem;
   int bj = blockIdx.x, job_id = 0;
@@ -357,6 +365,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   const int src_row = lane >> 2, src_sel = (lane >> 1) & 1, src_half = lane & 1;
   const char* dzb = reinterpret_cast<const char*>(a.dz);
   const char* acb = reinterpret_cast<const char*>(a.acts);
+  // every argument the loop needs, in SGPRs before it: a scalar load inside the loop shares lgkmcnt with the transposed reads and
+  // returns out of order, which makes hipcc wait with lgkmcnt(0) in front of every MFMA group (round 5)
+  long long zstride_b = a.zstride * 16, astride_b = a.astride * 16;
+  int z_lo = a.z_lo, a_lo = a.a_lo, dz_slot = jb.dz_slot, act_slot = jb.act_slot, nf = jb.nf, kf = jb.kf;
+  asm volatile("" : "+s"(zstride_b), "+s"(astride_b), "+s"(z_lo), "+s"(a_lo), "+s"(dz_slot), "+s"(act_slot), "+s"(nf), "+s"(kf));
 
   // every wave issues exactly DW_NPW DMAs per stage so that vmcnt arithmetic is uniform: pair blocks wv + DW_WAVES k
   auto issue = [&](int ht, int stage) {
@@ -376,36 +389,23 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
         const int nt_ = is_z ? n_tiles : k_tiles;
         const int lo_part = j >= nt_ ? 1 : 0;
         const int t = lo_part ? j - nt_ : j;
-        const int nfr = is_z ? jb.nf : jb.kf;
+        const int nfr = is_z ? nf : kf;
         int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;        // odd counts (rgb / alpha: nf = 1): rows past n_valid, never read back
-        const int slot = (is_z ? jb.dz_slot + lo_part * a.z_lo : jb.act_slot + lo_part * a.a_lo) + fr;
+        const int slot = (is_z ? dz_slot + lo_part * z_lo : act_slot + lo_part * a_lo) + fr;
 #if NERF_ABLATE == 9          // timing-only build 9: every DMA reads ONE contiguous KiB (wrong operands): what the two 512-byte halves cost
-        const char* src = (is_z ? dzb + tile * a.zstride * 16 : acb + tile * a.astride * 16) + (int64_t)(slot - src_sel + (ht & 1)) * 1024 + 16 * lane;
+        const char* src = (is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)(slot - src_sel + (ht & 1)) * 1024 + 16 * lane;
         (void)row_off;
 #else
-        const char* src = (is_z ? dzb + tile * a.zstride * 16 : acb + tile * a.astride * 16) + (int64_t)slot * 1024 + row_off;
+        const char* src = (is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)slot * 1024 + row_off;
 #endif
         dma_frag_nt(src, st + i * 1024);
       } else {
-        dma_frag(dzb + tile * a.zstride * 16 + (int64_t)jb.dz_slot * 1024 + 16 * lane, sink);   // padding: L2 hit, result unused
+        dma_frag(dzb + tile * zstride_b + (int64_t)dz_slot * 1024 + 16 * lane, sink);   // padding: L2 hit, result unused
       }
     }
   };
   const int ht_lo = 2 * tile_lo, ht_hi = 2 * tile_hi;
-#pragma unroll
-  for (int s_ = 0; s_ < DW_STAGES - 1; ++s_)
-    if (ht_lo + s_ < ht_hi) issue(ht_lo + s_, s_);
-
-  for (int ht = ht_lo; ht < ht_hi; ++ht) {
-    const int rem = ht_hi - 1 - ht;                       // stages issued after this one and still in flight (<= 2)
-    // lgkmcnt(0): this wave's transposed reads of the previous stage are complete before the barrier lets another wave's
-    // DMA refill it
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // stage landed for every wave; stage (ht - 1) % 4 is free
-    if (ht + DW_STAGES - 1 < ht_hi) issue(ht + DW_STAGES - 1, (ht - ht_lo + DW_STAGES - 1) % DW_STAGES);
-    const char* st = smem + ((ht - ht_lo) % DW_STAGES) * DW_STAGE_BYTES;
+  auto process = [&](const char* st) {
 #if NERF_ABLATE == 31         // timing-only build 31: the load skeleton alone (no transposed reads, no MFMAs)
     (void)st;
     if (false) {
@@ -447,6 +447,33 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
 #endif
       }
     }
+  };
+  if (PAIR) {
+    const int n = ht_hi - ht_lo;                          // even: two half tiles per sample tile
+    if (n > 0) { issue(ht_lo, 0); issue(ht_lo + 1, 1); }
+    for (int p = 0; p < n; p += 2) {
+      // the pair has landed (nothing younger is in flight); lgkmcnt(0): this wave's reads of the previous pair are complete
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // pair p landed for every wave; the slots of pair p - 2 are free
+      if (p + 2 < n) { issue(ht_lo + p + 2, (p + 2) % DW_STAGES); issue(ht_lo + p + 3, (p + 3) % DW_STAGES); }   // (one in front of each half: measured slower)
+      process(smem + (p % DW_STAGES) * DW_STAGE_BYTES);
+      process(smem + ((p + 1) % DW_STAGES) * DW_STAGE_BYTES);
+    }
+  } else {
+#pragma unroll
+    for (int s_ = 0; s_ < DW_STAGES - 1; ++s_)
+      if (ht_lo + s_ < ht_hi) issue(ht_lo + s_, s_);
+    for (int ht = ht_lo; ht < ht_hi; ++ht) {
+      const int rem = ht_hi - 1 - ht;                       // stages issued after this one and still in flight (<= 2)
+      // lgkmcnt(0): this wave's transposed reads of the previous stage are complete before the barrier lets another wave's
+      // DMA refill it
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // stage landed for every wave; stage (ht - 1) % 4 is free
+      if (ht + DW_STAGES - 1 < ht_hi) issue(ht + DW_STAGES - 1, (ht - ht_lo + DW_STAGES - 1) % DW_STAGES);
+      process(smem + ((ht - ht_lo) % DW_STAGES) * DW_STAGE_BYTES);
+    }
   }
   if (!active) return;
   const int rr = lane & 31, hh = lane >> 5;
@@ -471,7 +498,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// dW, 8-wave form with two operand register sets (round 5; the default, "dw22_variant" 1).
+// dW, 8-wave form with two operand register sets (round 5; "dw22_variant" 1; the default is the PAIR form of the 16-wave kernel above).
 // ------------------------------------------------------------------------------------------
 // What bounds s16_dw_kernel above is NOT HBM (round 4 said so): measured with tools/probe_dw22.py on timing-only builds and
 // tools/dw22_probe.hip --
@@ -486,7 +513,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
 // a 4-bit counter); the ring needs stage j + 1 landed one barrier earlier (still three half tiles in flight); the bias row sums
 // split between the two waves that share a dZ tile pair; every kernel argument the loop needs sits in SGPRs before it (a scalar
 // load inside the loop shares lgkmcnt with the reads and returns out of order: hipcc then waits with lgkmcnt(0) everywhere).
-// Measured: 3.74 against 3.79 ms (-1.5 %), bit-identical gradients -- hipcc still orders part of the next stage's reads in front
+// Measured: 3.72 against 3.78 ms (-1.5 %; the PAIR form of the 16-wave kernel: 3.42-3.46, -8 %), bit-identical gradients -- hipcc still orders part of the next stage's reads in front
 // of the current stage's first MFMAs with waits that count them (lgkmcnt(10), (5), (1), (0) in the ISA), so most of the intended
 // overlap is not realised.  Two further forms were measured and not kept: the reads as inline asm with our own wait (the twelve
 // 128-bit operands assembled from 64-bit halves cost 48 more registers: spills), and the operands fetched into registers by plain
@@ -737,15 +764,17 @@ int backward_chain(const void* packed_s16, const void* acts, const float* d_raw,
   return check_launch("mlp backward chain (split bf16)");
 }
 
-int g_dw_variant = 1;          // nerf_set_option("dw22_variant"): 1 (default) the software-pipelined 8-wave kernel, 0 the 16-wave kernel
+int g_dw_variant = 2;          // nerf_set_option("dw22_variant"): 2 (default) 16 waves, one barrier per sample tile; 1 the 8-wave kernel with two operand sets; 0 round 4's form
 
 int launch_dw_kernel(const DwArgs& d, int workgroups, hipStream_t s) {
   static DevOnce once;
   if (once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
   }
-  if (g_dw_variant == 0) hipLaunchKernelGGL(s16_dw_kernel, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
+  if (g_dw_variant == 0) hipLaunchKernelGGL(s16_dw_kernel<false>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
+  else if (g_dw_variant == 2) hipLaunchKernelGGL(s16_dw_kernel<true>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
   else hipLaunchKernelGGL(s16_dw2_kernel, dim3(workgroups), dim3(64 * DW2_WAVES), DW_LDS_BYTES, s, d);
   return check_launch("mlp dW (split bf16)");
 }

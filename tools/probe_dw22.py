@@ -14,7 +14,7 @@ rays=torch.cat([o,d,torch.full((B,1),2.0),torch.full((B,1),6.0),torch.nn.functio
 z=torch.sort(torch.rand(B,n,generator=g)*4+2,-1).values.to(dev); dr=(torch.randn(B,n,4,generator=g)*1e-4).to(dev)
 opt=lambda k,v: _native.check(_native.lib().nerf_set_option(k,v))
 ref = None
-for variant in (0, 1, 0, 1):
+for variant in (0, 1, 2, 0, 1, 2):
     opt(b"dw22_variant", variant)
     opt(b"bwd_stage", 0)
     m.query(rays,z,train=True); g_ = m.backward(dr).clone()
