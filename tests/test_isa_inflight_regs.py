@@ -64,7 +64,10 @@ def test_fp32_kernels_never_touch_a_register_ahead_of_its_wait(tmp_path):
 def test_m0_scanner_accepts_the_ring_statements_and_flags_compiler_uses(tmp_path):
     """csrc/check_m0.py (run by csrc/Makefile on the ISA of the split-precision kernels, which write M0 without restoring
     it): the ring's `s_mov_b32 m0, sN` + `global_load_lds` pairs pass, any other mention of M0 fails the scan."""
-    import check_m0
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("csrc_check_m0", os.path.join(ROOT, "nerf_meets_mlx_amd", "csrc", "check_m0.py"))
+    check_m0 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(check_m0)
     ok = tmp_path / "ok.s"
     ok.write_text("_ZN4nerf3f2216mlp22_fwd_kernelILi1EEEvNS_7FwdArgsE: ; @k\n\ts_mov_b32 m0, s12\n\ts_nop 0\n"
                   "\tglobal_load_lds_dwordx4 v3, s[4:5]\n\tv_mfma_f32_16x16x32_f16 v[0:3], v[4:7], a[0:3], v[0:3]\n.Lfunc_end0:\n")
@@ -77,6 +80,12 @@ def test_m0_scanner_accepts_the_ring_statements_and_flags_compiler_uses(tmp_path
     assert check_m0.main() == 1
     sys.argv = ["check_m0.py", str(ok), "--kernels", "no_such_kernel"]
     assert check_m0.main() == 2
+    # the save / restore form of the weight-gradient kernels (dma_frag / dma_frag_nt) is ours too; without --kernels every kernel is scanned
+    sr = tmp_path / "sr.s"
+    sr.write_text("_ZN4nerf3s1613s16_dw_kernelILb1EEEvNS_6DwArgsE: ; @k\n\ts_mov_b32 s7, m0\n\ts_mov_b32 m0, s12\n\ts_nop 0\n"
+                  "\tglobal_load_lds_dwordx4 v[2:3], off nt\n\ts_mov_b32 m0, s7\n.Lfunc_end0:\n")
+    sys.argv = ["check_m0.py", str(sr)]
+    assert check_m0.main() == 0
 
 
 def test_shipped_split_kernels_passed_the_build_time_scans():
@@ -89,7 +98,7 @@ def test_shipped_split_kernels_passed_the_build_time_scans():
         pytest.skip("no in-tree build directory (library built elsewhere)")
     # (object, kernels scanned, of which ring kernels that issue LDS-DMA): mlp_s16x's 2 x 64 kernels keep their weights LDS-resident
     # every kernel of a unit is scanned (round 5): pack kernels and the weight-gradient kernels included
-    for name, kernels, ring in (("mlp22_m0_scan.txt", 3, 2), ("mlp_s16_m0_scan.txt", 6, 5), ("mlp_s16x_m0_scan.txt", 10, 3)):
+    for name, kernels, ring in (("mlp22_m0_scan.txt", 3, 2), ("mlp_s16_m0_scan.txt", 7, 6), ("mlp_s16x_m0_scan.txt", 10, 3)):
         path = os.path.join(build, name)
         assert os.path.exists(path), f"{name} missing: the Makefile rule of the split kernels did not run"
         rows = [ln for ln in open(path) if "LDS-DMA M0 writes" in ln]
