@@ -345,7 +345,10 @@ int nerf_comm_destroy(void* comm);
  *                     5 same with 4 waves x 64 samples.  Training kernels use 3 for every value >= 3.
  *   "ring_workgroups" persistent workgroups of the ring kernels (0 = default: one per CU of the current device)
  *   "dw_workgroups"   0 auto (one per CU) | workgroups of the weight-gradient kernel
- *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (default 128)
+ *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (negative = automatic, the
+ *                     default: 128 for the bf16 kernel, 32 for the split-bf16 kernels)
+ *   "dw22_variant"    split-bf16 weight-gradient kernel: 2 (default) 16 waves, one barrier per sample tile | 1 eight waves, two operand
+ *                     register sets | 0 round 4's form.  Gradients are bit-identical across the three.
  *   "hash_combine_max_res"  table-gradient scatter: levels with N_l <= this value (default 64) accumulate in LDS first and
  *                     add each distinct table entry once (coarse levels collide heavily); 0 = every level directly
  *   "ngp_ray_major"   fused configs[4] inference query: 1 (default) a 32-sample tile is one depth of 32 adjacent rays (the

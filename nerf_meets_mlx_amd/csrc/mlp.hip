@@ -919,8 +919,12 @@ __global__ void __launch_bounds__(64 * DW_WAVES) mlp_dw_kernel(DwArgs a) {
   const int tile_hi = (int)((int64_t)a.ntiles * (bj + 1) / a.splits[job_id]);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wv >> 2, wc = wv & 3;                  // wave rows: DW_WAVES / 4
   const int n_tiles = (jb.nf + 1) >> 1, k_tiles = (jb.kf + 1) >> 1;
+  // wave (wr, wc) of the 4 x 4 wave grid.  A wave runs on SIMD wv % 4: with wr = wv / 4 the waves of one wave COLUMN share a SIMD,
+  // and a job with k_tiles <= 2 (pos0, pos5 | PE, dir0 | dirPE: only column 0 has work) puts all its MFMAs on SIMD 0 while three
+  // SIMDs idle.  Such jobs use the transposed numbering (round 5): their active waves are wv = 0..3, one per SIMD.
+  const bool col_major = DW_WAVES == 16 && k_tiles <= 2;
+  const int wr = col_major ? (wv & 3) : (wv >> 2), wc = col_major ? (wv >> 2) : (wv & 3);
   const int nf_pad = n_tiles * 2;
   const int nfk = jb.nf + jb.kf;                        // real fragments per sample tile (<= 32)
   // this wave's output tiles: n-tiles wr*DW_NPW + (0..DW_NPW-1), k-tiles wc*2 + (0..1)
@@ -1471,7 +1475,10 @@ __global__ void __launch_bounds__(512) mlp_small_bwd_kernel(SmallArgs a) {
 }
 
 static int g_dw_wgs = 0;       // 0: automatic (see launch_dw)
-static int g_dw_bias = 128;    // per-tile fixed cost of a dW job in fragment units (cost model of the static split)
+static int g_dw_bias = -1;     // per-tile fixed cost of a dW job in fragment units (cost model of the static split); -1 = automatic:
+                               // 128 for the bf16 kernel (round 2 sweep), 32 for the split-bf16 kernel (round 5: its stage boundary is
+                               // paid once per sample tile and narrow jobs use all four SIMDs, so a job's time follows its bytes more
+                               // closely: tools/sweep_dw22_bias.py, 3.30-3.34 ms at 16-48 against 3.47 at 128)
 static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW only (on whatever dz holds)
 static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
@@ -1566,7 +1573,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "ring_workgroups")) { g_ring_wgs = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "tile_pad16")) { g_tile_pad16 = value >= 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "dw_workgroups")) { g_dw_wgs = value > 0 ? value : 0; return NERF_OK; }
-  if (!strcmp(key, "dw_unit_bias")) { g_dw_bias = value >= 0 ? value : 0; return NERF_OK; }
+  if (!strcmp(key, "dw_unit_bias")) { g_dw_bias = value >= 0 ? value : -1; return NERF_OK; }
   if (!strcmp(key, "bwd_stage")) { g_bwd_stage = value; return NERF_OK; }
   if (!strcmp(key, "dw_job_mask")) { g_dw_job_mask = value; return NERF_OK; }
   if (!strcmp(key, "hash_combine_max_res")) { g_hash_combine_max_res = value > 0 ? value : 0; return NERF_OK; }
@@ -1831,7 +1838,7 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   // at a full grid, but under load the sweep over c0 keeps improving up to ~128 and is flat beyond (tools/sweep_dw.py).  Split the sample range of every job in proportion.
   int64_t units[DW_MAX_JOBS], total_units = 0;
   for (int j = 0; j < nj; ++j) {
-    units[j] = d.jobs[j].nf + d.jobs[j].kf + g_dw_bias;
+    units[j] = d.jobs[j].nf + d.jobs[j].kf + (g_dw_bias >= 0 ? g_dw_bias : split_bf16 ? 32 : 128);
     total_units += units[j];
   }
   // One workgroup per CU and launch (256), shares by largest remainder so that they sum to exactly 256: every

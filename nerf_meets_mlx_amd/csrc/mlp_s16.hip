@@ -344,8 +344,11 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   const int tile_hi = (int)((int64_t)a.ntiles * (bj + 1) / a.splits[job_id]);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wv >> 2, wc = wv & 3;
   const int n_tiles = (jb.nf + 1) >> 1, k_tiles = (jb.kf + 1) >> 1;
+  // wave (wr, wc) of the 4 x 4 wave grid; jobs whose work sits in wave column 0 only (k_tiles <= 2) number their waves column-major so
+  // that the active ones land on four different SIMDs (a wave runs on SIMD wv % 4; see mlp.hip:mlp_dw_kernel)
+  const bool col_major = k_tiles <= 2;
+  const int wr = col_major ? (wv & 3) : (wv >> 2), wc = col_major ? (wv >> 2) : (wv & 3);
   const int npairs = 2 * (n_tiles + k_tiles);             // real pair blocks per stage (<= 32)
   const bool active = (wr * DW_NPW < n_tiles) && (wc * 2 < k_tiles);
   f32x16 acc[DW_NPW][2];

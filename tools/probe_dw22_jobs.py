@@ -38,7 +38,7 @@ print(f"sum of single-job launches: {tot:.3f} ms")
 for bias in (32, 64, 128, 256, 512):
     opt(b"dw_unit_bias", bias)
     print(f"dw_unit_bias {bias}: {t_dw():.3f} ms")
-opt(b"dw_unit_bias", 128)
+opt(b"dw_unit_bias", -1)
 for wgs in (256, 512):
     opt(b"dw_workgroups", wgs)
     print(f"dw_workgroups {wgs}: {t_dw():.3f} ms")
