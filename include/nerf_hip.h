@@ -347,8 +347,10 @@ int nerf_comm_destroy(void* comm);
  *   "dw_workgroups"   0 auto (one per CU) | workgroups of the weight-gradient kernel
  *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (negative = automatic, the
  *                     default: 128 for the bf16 kernel, 32 for the split-bf16 kernels)
- *   "dw22_variant"    split-bf16 weight-gradient kernel: 2 (default) 16 waves, one barrier per sample tile | 1 eight waves, two operand
- *                     register sets | 0 round 4's form.  Gradients are bit-identical across the three.
+ *   "dw22_variant"    split-bf16 weight gradients: 1 (default) the 256 x 256 jobs on the one-wave-per-SIMD kernel (4 x 4 output tiles
+ *                     per wave, two operand register sets), the other jobs on the 16-wave kernel -- two launches | 0 every job on the
+ *                     16-wave kernel.  The two sum a tile's products and a bias row in different orders: gradients agree to ~1e-6
+ *                     rel-L2, each setting is bit-reproducible from run to run.
  *   "hash_combine_max_res"  table-gradient scatter: levels with N_l <= this value (default 64) accumulate in LDS first and
  *                     add each distinct table entry once (coarse levels collide heavily); 0 = every level directly
  *   "ngp_ray_major"   fused configs[4] inference query: 1 (default) a 32-sample tile is one depth of 32 adjacent rays (the

@@ -1578,7 +1578,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "dw_job_mask")) { g_dw_job_mask = value; return NERF_OK; }
   if (!strcmp(key, "hash_combine_max_res")) { g_hash_combine_max_res = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "ngp_ray_major")) { g_ngp_ray_major = value ? 1 : 0; return NERF_OK; }
-  if (!strcmp(key, "dw22_variant")) { s16::g_dw_variant = (value >= 0 && value <= 2) ? value : 1; return NERF_OK; }
+  if (!strcmp(key, "dw22_variant")) { s16::g_dw_variant = value == 0 ? 0 : 1; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -1830,9 +1830,11 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
 }
 
-// split the (dZ, H) jobs over workgroups and launch the dW kernel; grads[0..nparams) is overwritten
-static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
-                     int64_t zstride, float* grads, hipStream_t s, bool split_bf16 = false, int a_lo = 0, int z_lo = 0) {
+// one dW launch + its reduce over a job list.  kind 0: bf16 kernel (mlp_dw_kernel); 1: split bf16, 16 waves (s16_dw_kernel); 2: split bf16, 256 x 256 jobs only, one wave per SIMD
+// (s16_dww_kernel).  slot_base: first partial-tile slot of this launch (two launches of one backward pass use disjoint slots).
+static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
+                          int64_t zstride, float* grads, hipStream_t s, int kind, int a_lo, int z_lo, int slot_base, int max_wgs) {
+  const bool split_bf16 = kind != 0;
   // A job's cost per sample tile = its bytes (nf + kf KiB) + a fixed part (barrier, waits, the 4 DMA issues per wave,
   // transposed reads, MFMAs) worth about 128 KiB of streaming: single-job timings fit t = a (nf + kf + c0) with c0 = 24
   // at a full grid, but under load the sweep over c0 keeps improving up to ~128 and is flat beyond (tools/sweep_dw.py).  Split the sample range of every job in proportion.
@@ -1847,7 +1849,7 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   // for the 64-sample pass; with the old byte-only cost model 256 workgroups took 3.1 ms because the small jobs'
   // workgroups ran twice as long as the others.)  "dw_workgroups" overrides the total.
   int target_wgs = g_dw_wgs > 0 ? g_dw_wgs : cu_count();
-  if (target_wgs > DW_MAX_WGS) target_wgs = DW_MAX_WGS;          // one partial-tile slot per workgroup
+  if (target_wgs > max_wgs) target_wgs = max_wgs;               // one partial-tile slot per workgroup
   const int64_t max_splits = (ntiles + 3) / 4;                  // >= 4 sample tiles per workgroup
   int nw = 0;
   double frac[DW_MAX_JOBS];
@@ -1874,18 +1876,16 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
     if (d.splits[big] <= 1) break;
     d.splits[big] -= 1; nw -= 1;
   }
-  if (g_dw_job_mask) {          // diagnostic subset of jobs: the parameters of the jobs left out read as zero
-    hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * nparams, s);
-    if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
-  }
-  NERF_REQUIRE(nw <= DW_MAX_WGS, NERF_E_SHAPE, "nerf_mlp_backward: dw_workgroups must be <= %d", DW_MAX_WGS);
+  NERF_REQUIRE(slot_base + nw <= DW_MAX_WGS, NERF_E_SHAPE, "nerf_mlp_backward: dw_workgroups must be <= %d", DW_MAX_WGS);
   d.ntiles = (int)ntiles; d.astride = astride; d.zstride = zstride;
   d.acts = acts; d.dz = dz; d.grads = grads;
   d.a_lo = a_lo; d.z_lo = z_lo;
   // the partial-tile slots live behind the dZ fragment blocks in the caller's dz workspace (nerf_mlp_dz_bytes counts them)
-  d.partial = reinterpret_cast<float*>(static_cast<char*>(dz) + padded_tiles(ntiles * 32) * zstride * 16);
+  d.partial = reinterpret_cast<float*>(static_cast<char*>(dz) + padded_tiles(ntiles * 32) * zstride * 16) + (size_t)slot_base * DW_SLOT_FLOATS;
   int rc;
-  if (split_bf16) {            // hi + lo fragment blocks, three MFMAs per product (mlp_s16.hip); same jobs, slots and reduce
+  if (kind == 2) {             // 16 x 16-fragment jobs, one wave per SIMD (mlp_s16w.hip); same slots and reduce
+    rc = s16::launch_dw_wide_kernel(d, nw, s);
+  } else if (kind == 1) {      // hi + lo fragment blocks, three MFMAs per product (mlp_s16.hip); same jobs, slots and reduce
     rc = s16::launch_dw_kernel(d, nw, s);
   } else {
     static DevOnce lds_attr_set;
@@ -1897,6 +1897,37 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   if (rc) return rc;
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(257, nj), dim3(256), 0, s, d);        // 256 x 256 weights + 256 biases: one element per thread
   return check_launch("mlp dW reduce");
+}
+
+// split the (dZ, H) jobs over workgroups and launch the dW kernel(s); grads[0..nparams) is overwritten
+static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
+                     int64_t zstride, float* grads, hipStream_t s, bool split_bf16 = false, int a_lo = 0, int z_lo = 0) {
+  if (g_dw_job_mask) {          // diagnostic subset of jobs: the parameters of the jobs left out read as zero
+    hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * nparams, s);
+    if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
+  }
+  if (!split_bf16)
+    return launch_dw_part(d, nj, ntiles, nparams, acts, dz, astride, zstride, grads, s, 0, a_lo, z_lo, 0, DW_MAX_WGS);
+  if (s16::g_dw_variant == 0)
+    return launch_dw_part(d, nj, ntiles, nparams, acts, dz, astride, zstride, grads, s, 1, a_lo, z_lo, 0, DW_MAX_WGS);
+  // "dw22_variant" 1 (default): the 256 x 256 jobs on the one-wave-per-SIMD kernel, the others on the 16-wave kernel; two launches, each with
+  // its own static split over all CUs and its own half of the partial-tile slots
+  DwArgs wide = d, rest = d;
+  int nwide = 0, nrest = 0;
+  for (int j = 0; j < nj; ++j) {
+    if (d.jobs[j].nf == 16 && d.jobs[j].kf == 16) wide.jobs[nwide++] = d.jobs[j];
+    else rest.jobs[nrest++] = d.jobs[j];
+  }
+  const int half = DW_MAX_WGS / 2;
+  if (nwide) {
+    const int rc = launch_dw_part(wide, nwide, ntiles, nparams, acts, dz, astride, zstride, grads, s, 2, a_lo, z_lo, half, half);
+    if (rc) return rc;
+  }
+  if (nrest) {
+    const int rc = launch_dw_part(rest, nrest, ntiles, nparams, acts, dz, astride, zstride, grads, s, 1, a_lo, z_lo, 0, half);
+    if (rc) return rc;
+  }
+  return NERF_OK;
 }
 
 static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, const void* acts, const float* d_raw,

@@ -310,9 +310,15 @@ __global__ void __launch_bounds__(64 * NW) s16_bwd_kernel(BwdArgs a) {
 // tile side by side, so that a ds_read_b64_tr_b16 (4 sample rows x 2 fragments x 32 B per 32 lanes) covers 256 contiguous
 // bytes: every bank once, no padding.  One LDS-DMA fills one pair block; the per-lane SOURCE address does the shuffle
 // (lane i: row i >> 2, fragment (i >> 1) & 1, 16-byte half i & 1).  Blocks of a stage: dZ hi [n_tiles] | dZ lo [n_tiles] |
-// H hi [k_tiles] | H lo [k_tiles]  <= 32 KiB; four stages = three half tiles (<= 96 KiB) in flight behind the one in use.
-constexpr int DW_STAGE_BYTES = 32 * 1024, DW_STAGES = 4;
-constexpr int DW_LDS_BYTES = DW_STAGES * DW_STAGE_BYTES + 1024;   // + 1 KiB sink for padding DMAs
+// H hi [k_tiles] | H lo [k_tiles]  <= 32 KiB.
+#ifndef NERF_DWX
+#define NERF_DWX 0            // timing-only builds (bit mask): 1 no DMAs, 2 no transposed reads, 4 no stage barrier, 8 no bias sums, 16 no MFMAs
+#endif
+#if NERF_DWX & 4
+#define DW_BARRIER() do {} while (0)
+#else
+#define DW_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 constexpr int DW_WAVES = 16, DW_NPW = 2;                          // 2 x 2 output tiles per wave; 2 DMAs per wave per stage
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int i16) {
@@ -320,6 +326,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
   // order).  Lane i16 = 4 q + p of a 16-lane group addresses sample row q (and q + 4), feature piece p of fragment fsel.
   const int q = i16 >> 2, p = i16 & 3;
   const char* base = blk + 64 * (8 * hq + q) + 32 * fsel + 16 * (p & 1) + 8 * (p >> 1);
+#if NERF_DWX & 2
+  bf16x8 r; asm volatile("" : "=v"(r) : "v"(base)); return r;
+#endif
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 256));
   union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
@@ -327,14 +336,36 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
   return cvt.v;
 }
 
-// PAIR ("dw22_variant" 2, round 5): one barrier per TWO stages (a whole 32-sample tile): the pair is waited for, the barrier
-// frees the previous pair's slots, the next pair is issued into them (64 KiB in flight while 64 KiB are processed), then both
-// half tiles are processed back to back -- the fixed cost of a stage boundary (barrier skew, the refill DMAs' blocked issue, the
-// LDS latency in front of the first MFMA) is paid once per 24 MFMAs of a wave instead of once per 12.  Measured (tools/probe_dw22.py,
-// 786 k samples): 3.42-3.46 ms against 3.72-3.78 (-8 %), gradients bit-identical; the default since round 5.  (The kernel arguments
-// the loop needs are copied into SGPRs in front of it: with the stage body a lambda, hipcc re-loaded them inside the loop, and a
-// scalar load there makes it wait with lgkmcnt(0) in front of every MFMA group: 4.07 ms.)
-template <bool PAIR>
+// ------------------------------------------------------------------------------------------
+// the general dW kernel: 16 waves (4 x 4 waves of 2 x 2 output tiles), any job shape
+// ------------------------------------------------------------------------------------------
+// Since round 5 the 256 x 256 jobs run on mlp_s16w.hip's one-wave-per-SIMD kernel; this one takes the narrow jobs (input layers,
+// heads, the 2 x 64 model) and, with nerf_set_option("dw22_variant", 0), every job.
+//  * Ring: a stage takes npairs KiB, the ring all 160 KiB of the CU: 5 stages for a 256 x 256 job, up to 8 for the narrow ones.
+//    ONE barrier per sample tile (two stages): the pair is waited for, the barrier frees the slots of the pair before it, every
+//    stage whose slot is free is issued (two in steady state; ns - 2 stages stay in flight while a pair is processed), then both
+//    half tiles are processed back to back -- the fixed cost of a stage boundary (barrier skew, the refill DMAs' blocked issue,
+//    the LDS latency in front of the first MFMA) is paid once per 24 MFMAs of a wave instead of once per 12 (round 4's form: one
+//    barrier per stage, 3.72-3.78 ms for the 786 k-sample launch; this form 3.35-3.45).  No padding DMAs: a wave waits with
+//    vmcnt(its own DMAs per stage x the stages issued behind the pair).
+//  * Jobs with k_tiles <= 2 number their waves column-major: the active waves then sit on four SIMDs instead of one.
+//  * Every kernel argument the loop needs is copied into SGPRs in front of it: a scalar load inside the loop shares lgkmcnt with
+//    the transposed reads and returns out of order, which makes hipcc wait with lgkmcnt(0) in front of every MFMA group (4.07 ms).
+//  * Bias row sums (v_dot2c against (1, 1)) are spread over the waves of a row: (tile i, hi | lo part) c goes to wave column
+//    c % (active columns), combined through the LDS once at the end in a fixed order.  The branches around them are kept branches
+//    (empty asm): if-converted, every wave ran all sixteen v_dot2c and selected (+7 %).
+// What bounds it (tools/probe_dw22_chain.py on the NERF_DWX timing-only builds, 786 k samples, all jobs): MFMAs alone 1.87 ms
+// (the 256 x 256 workgroups at 0.78 us per stage, clock-limited), + barrier 0.06, + bias sums 0.3, + transposed reads 0.27 = 2.5 ms
+// without a single DMA; the load skeleton alone 2.6-2.8 ms (6.3-6.7 TB/s); together 3.35-3.45: a wave of 128 registers cannot
+// hold a second operand set, so reads and MFMAs of a stage are serial per wave and the four waves of a SIMD, in step behind the
+// barrier, overlap them only by drifting apart.  An 8-wave form with two operand sets (round 5, removed) measured 3.54-3.72:
+// two waves per SIMD in step leave the matrix pipe idle while both run their DMA / address / read instructions.  The 4-wave form
+// (mlp_s16w.hip) is what hides them.
+#ifndef NERF_DW_RING_CAP
+#define NERF_DW_RING_CAP 8
+#endif
+constexpr int DW_LDS_BYTES = 160 * 1024, DW_MAX_STAGES = NERF_DW_RING_CAP;
+
 __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   char* smem = ring_smem;
   int bj = blockIdx.x, job_id = 0;
@@ -345,12 +376,14 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_tiles = (jb.nf + 1) >> 1, k_tiles = (jb.kf + 1) >> 1;
-  // wave (wr, wc) of the 4 x 4 wave grid; jobs whose work sits in wave column 0 only (k_tiles <= 2) number their waves column-major so
-  // that the active ones land on four different SIMDs (a wave runs on SIMD wv % 4; see mlp.hip:mlp_dw_kernel)
-  const bool col_major = k_tiles <= 2;
+  const bool col_major = k_tiles <= 2;                    // see s16_dw_kernel
   const int wr = col_major ? (wv & 3) : (wv >> 2), wc = col_major ? (wv >> 2) : (wv & 3);
-  const int npairs = 2 * (n_tiles + k_tiles);             // real pair blocks per stage (<= 32)
+  const int npairs = 2 * (n_tiles + k_tiles);             // real pair blocks per stage (10 .. 32)
   const bool active = (wr * DW_NPW < n_tiles) && (wc * 2 < k_tiles);
+  const int kc = (k_tiles + 1) >> 1;                      // active wave columns (1, 2 or 4)
+  int stride = npairs * 1024, ns = DW_LDS_BYTES / stride;
+  if (ns > DW_MAX_STAGES) ns = DW_MAX_STAGES;
+  const int cnt_w = (wv < npairs ? 1 : 0) + (wv + DW_WAVES < npairs ? 1 : 0);   // this wave's DMAs per stage
   f32x16 acc[DW_NPW][2];
 #pragma unroll
   for (int i = 0; i < DW_NPW; ++i)
@@ -358,63 +391,46 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][k][e] = 0.0f;
-  float bsum[DW_NPW];
+  float bsum[2 * DW_NPW];                                 // [2 i + part]: part 0 = hi block, 1 = lo block of dZ tile i
+  bool own[2 * DW_NPW];                                   // wave-uniform
 #pragma unroll
-  for (int i = 0; i < DW_NPW; ++i) bsum[i] = 0.0f;
+  for (int c = 0; c < 2 * DW_NPW; ++c) { bsum[c] = 0.0f; own[c] = (c % kc) == wc && !(NERF_DWX & 8); }
   const int g16 = lane >> 4, i16 = lane & 15, hq = g16 >> 1, fsel = g16 & 1;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  const unsigned sink = lds0 + DW_STAGES * DW_STAGE_BYTES;
-  // per-lane part of a pair block's source address: sample row, fragment of the pair, 16-byte half
   const int src_row = lane >> 2, src_sel = (lane >> 1) & 1, src_half = lane & 1;
   const char* dzb = reinterpret_cast<const char*>(a.dz);
   const char* acb = reinterpret_cast<const char*>(a.acts);
-  // every argument the loop needs, in SGPRs before it: a scalar load inside the loop shares lgkmcnt with the transposed reads and
-  // returns out of order, which makes hipcc wait with lgkmcnt(0) in front of every MFMA group (round 5)
   long long zstride_b = a.zstride * 16, astride_b = a.astride * 16;
   int z_lo = a.z_lo, a_lo = a.a_lo, dz_slot = jb.dz_slot, act_slot = jb.act_slot, nf = jb.nf, kf = jb.kf;
-  asm volatile("" : "+s"(zstride_b), "+s"(astride_b), "+s"(z_lo), "+s"(a_lo), "+s"(dz_slot), "+s"(act_slot), "+s"(nf), "+s"(kf));
+  asm volatile("" : "+s"(zstride_b), "+s"(astride_b), "+s"(z_lo), "+s"(a_lo), "+s"(dz_slot), "+s"(act_slot), "+s"(nf), "+s"(kf),
+               "+s"(stride), "+s"(ns));
 
-  // every wave issues exactly DW_NPW DMAs per stage so that vmcnt arithmetic is uniform: pair blocks wv + DW_WAVES k
-  auto issue = [&](int ht, int stage) {
-    const unsigned st = lds0 + __builtin_amdgcn_readfirstlane(stage) * DW_STAGE_BYTES;
-#if NERF_ABLATE == 32         // timing-only build 32: every stage re-reads the job's first sample tile (L2-resident): the compute path without HBM
-    const int64_t tile = tile_lo;
-#else
-    const int64_t tile = ht >> 1;
+  auto issue = [&](int ht, int slot) {
+#if NERF_DWX & 1
+    return;
 #endif
+    const unsigned st = lds0 + __builtin_amdgcn_readfirstlane(slot) * stride;
+    const int64_t tile = ht >> 1;
     const unsigned row_off = (unsigned)(32 * (16 * (ht & 1) + src_row) + 16 * src_half);
 #pragma unroll
     for (int k = 0; k < DW_NPW; ++k) {
       const int i = wv + DW_WAVES * k;                     // wave-uniform
       if (i < npairs) {
         const bool is_z = i < 2 * n_tiles;
-        const int j = is_z ? i : i - 2 * n_tiles;          // index inside the dZ / H half of the stage
+        const int j = is_z ? i : i - 2 * n_tiles;
         const int nt_ = is_z ? n_tiles : k_tiles;
         const int lo_part = j >= nt_ ? 1 : 0;
         const int t = lo_part ? j - nt_ : j;
         const int nfr = is_z ? nf : kf;
-        int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;        // odd counts (rgb / alpha: nf = 1): rows past n_valid, never read back
-        const int slot = (is_z ? dz_slot + lo_part * z_lo : act_slot + lo_part * a_lo) + fr;
-#if NERF_ABLATE == 9          // timing-only build 9: every DMA reads ONE contiguous KiB (wrong operands): what the two 512-byte halves cost
-        const char* src = (is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)(slot - src_sel + (ht & 1)) * 1024 + 16 * lane;
-        (void)row_off;
-#else
-        const char* src = (is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)slot * 1024 + row_off;
-#endif
+        int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;
+        const int slot_ = (is_z ? dz_slot + lo_part * z_lo : act_slot + lo_part * a_lo) + fr;
+        const char* src = (is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)slot_ * 1024 + row_off;
         dma_frag_nt(src, st + i * 1024);
-      } else {
-        dma_frag(dzb + tile * zstride_b + (int64_t)dz_slot * 1024 + 16 * lane, sink);   // padding: L2 hit, result unused
       }
     }
   };
-  const int ht_lo = 2 * tile_lo, ht_hi = 2 * tile_hi;
   auto process = [&](const char* st) {
-#if NERF_ABLATE == 31         // timing-only build 31: the load skeleton alone (no transposed reads, no MFMAs)
-    (void)st;
-    if (false) {
-#else
     if (active) {
-#endif
       bf16x8 bh[2], bl[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -429,16 +445,20 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
         const int b = nt < n_tiles ? nt : 0;
         const bf16x8 ah = tr_pair(st + b * 1024, hq, fsel, i16);
         const bf16x8 al = tr_pair(st + (b + n_tiles) * 1024, hq, fsel, i16);
-        if (wc == 0) {                         // bias gradient = row sums of dZ = hi + lo: v_dot2c_f32_bf16 against (1, 1)
-          const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+        const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+        // bias gradient = row sums of dZ: v_dot2c_f32_bf16 against (1, 1).  (The empty asm keeps the wave-uniform branch a branch:
+        // hipcc otherwise runs all sixteen v_dot2c on every wave and selects with v_cndmask.)
+        if (own[2 * i]) {
+          asm volatile("" ::: "memory");
 #pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            const bf16x2 ph = {ah[j], ah[j + 1]}, pl = {al[j], al[j + 1]};
-            bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pl, ones, bsum[i], false);
-            bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(ph, ones, bsum[i], false);
-          }
+          for (int j = 0; j < 8; j += 2) { const bf16x2 q = {ah[j], ah[j + 1]}; bsum[2 * i] = __builtin_amdgcn_fdot2_f32_bf16(q, ones, bsum[2 * i], false); }
         }
-#if NERF_ABLATE == 30         // timing-only build 30: transposed reads kept (and waited for), no MFMAs
+        if (own[2 * i + 1]) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) { const bf16x2 q = {al[j], al[j + 1]}; bsum[2 * i + 1] = __builtin_amdgcn_fdot2_f32_bf16(q, ones, bsum[2 * i + 1], false); }
+        }
+#if NERF_DWX & 16
         asm volatile("" :: "v"(ah), "v"(al), "v"(bh[0]), "v"(bl[0]), "v"(bh[1]), "v"(bl[1]));
 #else
 #pragma unroll
@@ -451,33 +471,43 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
       }
     }
   };
-  if (PAIR) {
-    const int n = ht_hi - ht_lo;                          // even: two half tiles per sample tile
-    if (n > 0) { issue(ht_lo, 0); issue(ht_lo + 1, 1); }
-    for (int p = 0; p < n; p += 2) {
-      // the pair has landed (nothing younger is in flight); lgkmcnt(0): this wave's reads of the previous pair are complete
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                       // pair p landed for every wave; the slots of pair p - 2 are free
-      if (p + 2 < n) { issue(ht_lo + p + 2, (p + 2) % DW_STAGES); issue(ht_lo + p + 3, (p + 3) % DW_STAGES); }   // (one in front of each half: measured slower)
-      process(smem + (p % DW_STAGES) * DW_STAGE_BYTES);
-      process(smem + ((p + 1) % DW_STAGES) * DW_STAGE_BYTES);
+  // wait until this wave's DMAs of everything but the `younger` most recently issued stages have landed (wave-uniform, <= 6 stages
+  // x <= 2 DMAs), and until its own transposed reads of the previous pair are complete
+  auto wait_landed = [&](int younger) {
+    switch (younger * cnt_w) {
+      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
     }
-  } else {
+  };
+  const int ht_lo = 2 * tile_lo, n = 2 * (tile_hi - tile_lo);   // stages of this workgroup (even: two per sample tile)
+  int issued = 0, slot_i = 0, slot_p = 0;                  // stages issued so far; the slot the next issue / the next process uses
+  for (; issued < ns && issued < n; ++issued) { issue(ht_lo + issued, slot_i); slot_i = slot_i + 1 == ns ? 0 : slot_i + 1; }
+  for (int p = 0; p < n; p += 2) {
+    wait_landed(issued - (p + 2));                         // stages p, p + 1 landed (this wave's part)
+    DW_BARRIER();                                          // ... for every wave; every wave is done with the stages before p
 #pragma unroll
-    for (int s_ = 0; s_ < DW_STAGES - 1; ++s_)
-      if (ht_lo + s_ < ht_hi) issue(ht_lo + s_, s_);
-    for (int ht = ht_lo; ht < ht_hi; ++ht) {
-      const int rem = ht_hi - 1 - ht;                       // stages issued after this one and still in flight (<= 2)
-      // lgkmcnt(0): this wave's transposed reads of the previous stage are complete before the barrier lets another wave's
-      // DMA refill it
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else if (rem == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                         // stage landed for every wave; stage (ht - 1) % 4 is free
-      if (ht + DW_STAGES - 1 < ht_hi) issue(ht + DW_STAGES - 1, (ht - ht_lo + DW_STAGES - 1) % DW_STAGES);
-      process(smem + ((ht - ht_lo) % DW_STAGES) * DW_STAGE_BYTES);
-    }
+    for (int k = 0; k < 2; ++k)                            // the slots of stages < p are free: stage s may go once s - ns < p
+      if (issued < n && issued - ns < p) { issue(ht_lo + issued, slot_i); slot_i = slot_i + 1 == ns ? 0 : slot_i + 1; ++issued; }
+    process(smem + slot_p * stride); slot_p = slot_p + 1 == ns ? 0 : slot_p + 1;
+    process(smem + slot_p * stride); slot_p = slot_p + 1 == ns ? 0 : slot_p + 1;
   }
+  // bias partial sums of a wave row -> its wc == 0 wave, through the LDS (every wave takes part in the two barriers)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float* xb = reinterpret_cast<float*>(smem);              // [wr][c][lane]
+#pragma unroll
+  for (int c = 0; c < 2 * DW_NPW; ++c)
+    if (own[c] && active) xb[(wr * 2 * DW_NPW + c) * 64 + lane] = bsum[c];
+  __builtin_amdgcn_s_barrier();
   if (!active) return;
   const int rr = lane & 31, hh = lane >> 5;
   float* slot = a.partial + (size_t)blockIdx.x * DW_SLOT_FLOATS;
@@ -494,217 +524,9 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
       for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32 + rr] = acc[i][k][e];      // 128 B per half wave
     }
     if (wc == 0 && jb.b_off >= 0) {
-      const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // the two sample halves of the k-step
-      if (hh == 0) slot[64 * 1024 + 32 * nt + rr] = tot;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// dW, 8-wave form with two operand register sets (round 5; "dw22_variant" 1; the default is the PAIR form of the 16-wave kernel above).
-// ------------------------------------------------------------------------------------------
-// What bounds s16_dw_kernel above is NOT HBM (round 4 said so): measured with tools/probe_dw22.py on timing-only builds and
-// tools/dw22_probe.hip --
-//   * its load skeleton alone (no transposed reads, no MFMAs) moves the 17.5 GB of a 786 k-sample launch in 2.61 ms = 6.7 TB/s;
-//   * with the operands L2-resident (every stage re-reads one sample tile: no HBM traffic at all) the kernel still takes 3.60 of
-//     its 3.78 ms; reads without MFMAs 2.71 ms; register-only MFMAs beside the load skeleton: no slowdown (6.6 TB/s);
-// i.e. the per-stage chain  barrier -> transposed reads -> wait -> MFMAs  of single-buffered operands, run by waves that the stage
-// barrier keeps in lock-step: 1.7 us per stage against 0.7 us of MFMA time per SIMD and 1.25 us of load time.
-// This form: 8 waves (two per SIMD, 256 registers each) instead of 16; wave (wr, wc) = 2 n-tiles x 4 k-tiles = 8 accumulator
-// tiles, 24 MFMAs per stage against 12 operand tiles read (the 16-wave form: 12 against 8: 25 % fewer LDS reads per MFMA); TWO
-// operand register sets: the transposed reads of stage j + 1 are issued between the MFMAs of stage j, in halves of 12 (lgkmcnt is
-// a 4-bit counter); the ring needs stage j + 1 landed one barrier earlier (still three half tiles in flight); the bias row sums
-// split between the two waves that share a dZ tile pair; every kernel argument the loop needs sits in SGPRs before it (a scalar
-// load inside the loop shares lgkmcnt with the reads and returns out of order: hipcc then waits with lgkmcnt(0) everywhere).
-// Measured: 3.72 against 3.78 ms (-1.5 %; the PAIR form of the 16-wave kernel: 3.42-3.46, -8 %), bit-identical gradients -- hipcc still orders part of the next stage's reads in front
-// of the current stage's first MFMAs with waits that count them (lgkmcnt(10), (5), (1), (0) in the ISA), so most of the intended
-// overlap is not realised.  Two further forms were measured and not kept: the reads as inline asm with our own wait (the twelve
-// 128-bit operands assembled from 64-bit halves cost 48 more registers: spills), and the operands fetched into registers by plain
-// global loads + ds_write_b128 instead of LDS-DMA (-2.5 %; at 127 of 128 registers hipcc re-used in-flight load destinations --
-// tools/check_inflight_regs.py: 90 hits, wrong gradients).  The floor this kernel is still 40 % above is its 2.6 ms of loads; what
-// reaches it is a hand-scheduled inner loop (operand reads of stage j + 1 strictly under the MFMAs of stage j), not another C++
-// arrangement of the same statements.
-// Same stages, pair blocks, job table, partial-tile slots and reduce kernel as above; gradients bit-identical to the 16-wave form.
-constexpr int DW2_WAVES = 8, DW2_NN = 2, DW2_NK = 4, DW2_DPW = 4;          // 4 DMAs per wave per stage
-
-struct DwOps { bf16x8 ah[DW2_NN], al[DW2_NN], bh[DW2_NK], bl[DW2_NK]; };
-
-__global__ void __launch_bounds__(64 * DW2_WAVES) s16_dw2_kernel(DwArgs a) {
-  char* smem = ring_smem;
-  int bj = blockIdx.x, job_id = 0;
-  while (bj >= a.splits[job_id]) { bj -= a.splits[job_id]; ++job_id; }
-  const DwJob jb = a.jobs[job_id];
-  const int tile_lo = (int)((int64_t)a.ntiles * bj / a.splits[job_id]);
-  const int tile_hi = (int)((int64_t)a.ntiles * (bj + 1) / a.splits[job_id]);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wv >> 1, wc = wv & 1;
-  const int n_tiles = (jb.nf + 1) >> 1, k_tiles = (jb.kf + 1) >> 1;
-  const int npairs = 2 * (n_tiles + k_tiles);             // real pair blocks per stage (<= 32)
-  const bool active = (wr * DW2_NN < n_tiles) && (wc * DW2_NK < k_tiles);
-  const int kn = k_tiles - wc * DW2_NK;                    // k-tiles of this wave that exist (wave-uniform; <= 0: inactive)
-  f32x16 acc[DW2_NN][DW2_NK];
-#pragma unroll
-  for (int i = 0; i < DW2_NN; ++i)
-#pragma unroll
-    for (int k = 0; k < DW2_NK; ++k)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][k][e] = 0.0f;
-  // bias gradient: the rows of dZ tile 2 wr + i are summed by wave (wr, wc = i) -- or, when the job has one k-column of waves only
-  // (k_tiles <= 4: wc == 1 is inactive), both by wave (wr, 0)
-  float bsum[DW2_NN] = {0.0f, 0.0f};
-  const bool one_col = k_tiles <= DW2_NK;
-  const bool sums0 = wc == 0, sums1 = wc == 1 || one_col;  // wave-uniform
-  const int g16 = lane >> 4, i16 = lane & 15, hq = g16 >> 1, fsel = g16 & 1;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  const unsigned sink = lds0 + DW_STAGES * DW_STAGE_BYTES;
-  const int src_row = lane >> 2, src_sel = (lane >> 1) & 1, src_half = lane & 1;
-  const char* dzb = reinterpret_cast<const char*>(a.dz);
-  const char* acb = reinterpret_cast<const char*>(a.acts);
-  // Everything the loop needs of the argument block is read into SGPRs HERE: a scalar load inside the loop shares lgkmcnt with the
-  // transposed reads and returns out of order, which makes hipcc wait with lgkmcnt(0) in front of every MFMA group (no overlap)
-  long long zstride_b = a.zstride * 16, astride_b = a.astride * 16;
-  int z_lo = a.z_lo, a_lo = a.a_lo, dz_slot = jb.dz_slot, act_slot = jb.act_slot, nf = jb.nf, kf = jb.kf;
-  asm volatile("" : "+s"(zstride_b), "+s"(astride_b), "+s"(z_lo), "+s"(a_lo), "+s"(dz_slot), "+s"(act_slot), "+s"(nf), "+s"(kf));
-
-  // every wave issues exactly DW2_DPW DMAs per stage so that vmcnt arithmetic is uniform: pair blocks wv + DW2_WAVES k
-  auto issue = [&](int ht, int stage) {
-    const unsigned st = lds0 + __builtin_amdgcn_readfirstlane(stage) * DW_STAGE_BYTES;
-    const int64_t tile = ht >> 1;
-    const unsigned row_off = (unsigned)(32 * (16 * (ht & 1) + src_row) + 16 * src_half);
-#pragma unroll
-    for (int k = 0; k < DW2_DPW; ++k) {
-      const int i = wv + DW2_WAVES * k;                    // wave-uniform
-      if (i < npairs) {
-        const bool is_z = i < 2 * n_tiles;
-        const int j = is_z ? i : i - 2 * n_tiles;
-        const int nt_ = is_z ? n_tiles : k_tiles;
-        const int lo_part = j >= nt_ ? 1 : 0;
-        const int t = lo_part ? j - nt_ : j;
-        const int nfr = is_z ? nf : kf;
-        int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;
-        const int slot = (is_z ? dz_slot + lo_part * z_lo : act_slot + lo_part * a_lo) + fr;
-        const char* src = (is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)slot * 1024 + row_off;
-        dma_frag_nt(src, st + i * 1024);
-      } else {
-        dma_frag(dzb + tile * zstride_b + (int64_t)dz_slot * 1024 + 16 * lane, sink);   // padding: L2 hit, result unused
-      }
-    }
-  };
-  // Operand tiles of one stage -> registers (transposed reads; tiles past the job's edge read a valid block, their products are
-  // never stored), in TWO halves of 12 reads: lgkmcnt is a 4-bit counter, so hipcc can express "the older set has arrived, the
-  // 12 reads just issued may stay in flight" (lgkmcnt(12)) but not the same with 24 behind it -- issued in one piece, the next
-  // stage's reads were followed by lgkmcnt(0) and nothing overlapped (measured: 4.10 ms against the 16-wave kernel's 3.78).
-  auto load_z = [&](const char* st, DwOps& o) {            // dZ tiles + the first k-tile: 12 reads
-#pragma unroll
-    for (int i = 0; i < DW2_NN; ++i) {
-      const int nt = wr * DW2_NN + i, b = nt < n_tiles ? nt : 0;
-      o.ah[i] = tr_pair(st + b * 1024, hq, fsel, i16);
-      o.al[i] = tr_pair(st + (b + n_tiles) * 1024, hq, fsel, i16);
-    }
-    const int kt = wc * DW2_NK, b = 2 * n_tiles + (kt < k_tiles ? kt : 0);
-    o.bh[0] = tr_pair(st + b * 1024, hq, fsel, i16);
-    o.bl[0] = tr_pair(st + (b + k_tiles) * 1024, hq, fsel, i16);
-  };
-  auto load_h = [&](const char* st, DwOps& o) {            // the other three k-tiles: 12 reads
-#pragma unroll
-    for (int k = 1; k < DW2_NK; ++k) {
-      const int kt = wc * DW2_NK + k, b = 2 * n_tiles + (kt < k_tiles ? kt : 0);
-      o.bh[k] = tr_pair(st + b * 1024, hq, fsel, i16);
-      o.bl[k] = tr_pair(st + (b + k_tiles) * 1024, hq, fsel, i16);
-    }
-  };
-  auto bias_sums = [&](const DwOps& o) {
-#pragma unroll
-    for (int i = 0; i < DW2_NN; ++i) {                     // row sums of dZ = hi + lo: v_dot2c_f32_bf16 against (1, 1)
-      if (i == 0 ? sums0 : sums1) {
-        const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const bf16x2 ph = {o.ah[i][j], o.ah[i][j + 1]}, pl = {o.al[i][j], o.al[i][j + 1]};
-          bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pl, ones, bsum[i], false);
-          bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(ph, ones, bsum[i], false);
-        }
-      }
-    }
-  };
-  auto mfmas = [&](const DwOps& o, int k0, int k1) {
-#pragma unroll
-    for (int k = 0; k < DW2_NK; ++k) {
-      if (k >= k0 && k < k1 && k < kn) {                   // wave-uniform
-#pragma unroll
-        for (int i = 0; i < DW2_NN; ++i) {
-          acc[i][k] = mfma32(o.al[i], o.bh[k], acc[i][k]);
-          acc[i][k] = mfma32(o.ah[i], o.bl[k], acc[i][k]);
-          acc[i][k] = mfma32(o.ah[i], o.bh[k], acc[i][k]);
-        }
-      }
-    }
-  };
-  const int ht_lo = 2 * tile_lo, n = 2 * (tile_hi - tile_lo);
-  // wait until this wave's DMAs of stage j have landed: the stages issued behind it (at most two more exist and are in flight)
-  auto wait_stage = [&](int j) {
-    const int younger = n - 1 - j;                         // wave-uniform
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-#pragma unroll
-  for (int s_ = 0; s_ < DW_STAGES - 1; ++s_)
-    if (s_ < n) issue(ht_lo + s_, s_);
-  DwOps o0, o1;
-  if (n > 0) {
-    wait_stage(0);
-    __builtin_amdgcn_s_barrier();                          // stage 0 landed for every wave
-    if (DW_STAGES - 1 < n) issue(ht_lo + DW_STAGES - 1, DW_STAGES - 1);
-    if (active) { load_z(smem, o0); load_h(smem, o0); }
-  }
-  // step j: `use` holds (or is receiving) the operands of stage j; the reads of stage j + 1 go to `load` between the MFMAs
-  auto step = [&](DwOps& use, DwOps& load, int j) {
-    const bool more = j + 1 < n;
-    const char* nst = smem + ((j + 1) % DW_STAGES) * DW_STAGE_BYTES;
-    if (more) {
-      // stages j + 2 and j + 3 may stay in flight (j + 3 was issued behind the previous barrier); lgkmcnt(0): this wave's
-      // transposed reads of stage j are complete before the barrier lets another wave's DMA refill that slot
-      const int younger = n - 2 - j;
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // stage j + 1 landed for every wave; slot of stage j is free
-      if (j + DW_STAGES < n) issue(ht_lo + j + DW_STAGES, j % DW_STAGES);
-      if (active) load_z(nst, load);
-      __builtin_amdgcn_sched_barrier(0);                   // the reads stay ahead of the MFMAs below
-    }
-    if (active) { bias_sums(use); mfmas(use, 0, 2); }
-    if (more && active) load_h(nst, load);
-    __builtin_amdgcn_sched_barrier(0);
-    if (active) mfmas(use, 2, DW2_NK);
-  };
-  for (int j = 0; j < n; j += 2) {
-    step(o0, o1, j);
-    if (j + 1 < n) step(o1, o0, j + 1);
-  }
-  if (!active) return;
-  const int rr = lane & 31, hh = lane >> 5;
-  float* slot = a.partial + (size_t)blockIdx.x * DW_SLOT_FLOATS;
-#pragma unroll
-  for (int i = 0; i < DW2_NN; ++i) {
-    const int nt = wr * DW2_NN + i;
-    if (nt >= n_tiles) continue;
-#pragma unroll
-    for (int k = 0; k < DW2_NK; ++k) {
-      const int kt = wc * DW2_NK + k;
-      if (kt >= k_tiles) continue;
-      float* tile = slot + (8 * nt + kt) * 1024;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32 + rr] = acc[i][k][e];      // 128 B per half wave
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < DW2_NN; ++i) {
-    const int nt = wr * DW2_NN + i;
-    if (jb.b_off >= 0 && nt < n_tiles && (i == 0 ? sums0 : sums1)) {
-      const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // the two sample halves of the k-step
+      const float lo = xb[(wr * 2 * DW_NPW + 2 * i + 1) * 64 + lane], hi = xb[(wr * 2 * DW_NPW + 2 * i) * 64 + lane];
+      const float t = lo + hi;
+      const float tot = t + __shfl_xor(t, 32, 64);         // the two sample halves of the k-step
       if (hh == 0) slot[64 * 1024 + 32 * nt + rr] = tot;
     }
   }
@@ -767,18 +589,13 @@ int backward_chain(const void* packed_s16, const void* acts, const float* d_raw,
   return check_launch("mlp backward chain (split bf16)");
 }
 
-int g_dw_variant = 2;          // nerf_set_option("dw22_variant"): 2 (default) 16 waves, one barrier per sample tile; 1 the 8-wave kernel with two operand sets; 0 round 4's form
+int g_dw_variant = 1;          // nerf_set_option("dw22_variant"): 1 (default) 256 x 256 jobs on mlp_s16w.hip's kernel, the others here; 0 every job here
 
 int launch_dw_kernel(const DwArgs& d, int workgroups, hipStream_t s) {
   static DevOnce once;
-  if (once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-  }
-  if (g_dw_variant == 0) hipLaunchKernelGGL(s16_dw_kernel<false>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
-  else if (g_dw_variant == 2) hipLaunchKernelGGL(s16_dw_kernel<true>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
-  else hipLaunchKernelGGL(s16_dw2_kernel, dim3(workgroups), dim3(64 * DW2_WAVES), DW_LDS_BYTES, s, d);
+  if (once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+  hipLaunchKernelGGL(s16_dw_kernel, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
   return check_launch("mlp dW (split bf16)");
 }
 

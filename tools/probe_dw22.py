@@ -1,6 +1,6 @@
 """Split-bf16 backward at the bench's fine-pass size (4096 x 192 samples), chain and dW timed separately (nerf_set_option
-"bwd_stage"), the dW kernel in its two forms ("dw22_variant": 0 = 16 waves / single operand set (round 4), 1 = 8 waves / two operand
-register sets); with NERF_HIP_LIB pointing at a timing-only build an A/B probe."""
+"bwd_stage"), the weight gradients in both settings of "dw22_variant" (1 = 256 x 256 jobs on the one-wave-per-SIMD kernel + the rest
+on the 16-wave kernel, the default; 0 = every job on the 16-wave kernel); with NERF_HIP_LIB pointing at a timing-only build an A/B probe."""
 import os, sys, torch
 sys.path.insert(0, ".")
 from nerf_meets_mlx_amd import _native
@@ -14,7 +14,7 @@ rays=torch.cat([o,d,torch.full((B,1),2.0),torch.full((B,1),6.0),torch.nn.functio
 z=torch.sort(torch.rand(B,n,generator=g)*4+2,-1).values.to(dev); dr=(torch.randn(B,n,4,generator=g)*1e-4).to(dev)
 opt=lambda k,v: _native.check(_native.lib().nerf_set_option(k,v))
 ref = None
-for variant in (0, 1, 2, 0, 1, 2):
+for variant in (0, 1, 0, 1):
     opt(b"dw22_variant", variant)
     opt(b"bwd_stage", 0)
     m.query(rays,z,train=True); g_ = m.backward(dr).clone()

@@ -12,7 +12,7 @@ o=torch.nn.functional.normalize(torch.randn(B,3,generator=g),dim=-1)*4; d=-o/4+0
 rays=torch.cat([o,d,torch.full((B,1),2.0),torch.full((B,1),6.0),torch.nn.functional.normalize(d,dim=-1)],-1).to(dev)
 z=torch.sort(torch.rand(B,n,generator=g)*4+2,-1).values.to(dev); dr=(torch.randn(B,n,4,generator=g)*1e-4).to(dev)
 opt=lambda k,v: _native.check(_native.lib().nerf_set_option(k,v))
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 1     # "dw22_variant": 1 the default (two kernels), 0 every job on the 16-wave kernel
 opt(b"dw22_variant", variant)
 m.query(rays,z,train=True); m.backward(dr)
 opt(b"bwd_stage", 2)

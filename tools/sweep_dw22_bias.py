@@ -6,6 +6,7 @@ from nerf_meets_mlx_amd import _native
 from nerf_meets_mlx_amd.models.NeRF import NeRF
 dev="cuda"
 opt=lambda k,v: _native.check(_native.lib().nerf_set_option(k,v))
+if len(sys.argv) > 1: opt(b"dw22_variant", int(sys.argv[1]))     # default: the shipped kernel
 for B,n in ((4096,192),(4096,64)):
     m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0, precision=22)
     g=torch.Generator().manual_seed(0)
