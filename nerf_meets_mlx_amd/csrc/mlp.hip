@@ -1480,6 +1480,7 @@ static int g_dw_bias = -1;     // per-tile fixed cost of a dW job in fragment un
                                // paid once per sample tile and narrow jobs use all four SIMDs, so a job's time follows its bytes more
                                // closely: tools/sweep_dw22_bias.py, 3.30-3.34 ms at 16-48 against 3.47 at 128)
 static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW only (on whatever dz holds)
+static int g_dw16_variant = 1;  // "dw16_variant": bf16 weight gradients, 1 = 256 x 256 jobs on mlp_dww.hip's kernel (default), 0 = every job on mlp_dw_kernel
 static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
 static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
@@ -1579,6 +1580,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "hash_combine_max_res")) { g_hash_combine_max_res = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "ngp_ray_major")) { g_ngp_ray_major = value ? 1 : 0; return NERF_OK; }
   if (!strcmp(key, "dw22_variant")) { s16::g_dw_variant = value == 0 ? 0 : 1; return NERF_OK; }
+  if (!strcmp(key, "dw16_variant")) { g_dw16_variant = value == 0 ? 0 : 1; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -1591,6 +1593,7 @@ extern "C" int nerf_get_option(const char* key) {
   if (!strcmp(key, "hash_combine_max_res")) return g_hash_combine_max_res;
   if (!strcmp(key, "ngp_ray_major")) return g_ngp_ray_major;
   if (!strcmp(key, "dw22_variant")) return s16::g_dw_variant;
+  if (!strcmp(key, "dw16_variant")) return g_dw16_variant;
   return -1;
 }
 
@@ -1830,11 +1833,12 @@ extern "C" int nerf_query_fused(const nerf_mlp_arch* arch, const void* packed, c
   return launch_fwd<1>(packed, nullptr, rays, z, B * n, n, freq_mode, raw, acts, stream);
 }
 
-// one dW launch + its reduce over a job list.  kind 0: bf16 kernel (mlp_dw_kernel); 1: split bf16, 16 waves (s16_dw_kernel); 2: split bf16, 256 x 256 jobs only, one wave per SIMD
-// (s16_dww_kernel).  slot_base: first partial-tile slot of this launch (two launches of one backward pass use disjoint slots).
+// one dW launch + its reduce over a job list.  kind 0: bf16, 16 waves (mlp_dw_kernel); 1: split bf16, 16 waves (s16_dw_kernel);
+// 2 / 3: split bf16 / bf16, 256 x 256 jobs only, one wave per SIMD (mlp_dww_kernel).  slot_base: first partial-tile slot of this
+// launch (the two launches of one backward pass use disjoint slots).
 static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const void* acts, void* dz, int64_t astride,
                           int64_t zstride, float* grads, hipStream_t s, int kind, int a_lo, int z_lo, int slot_base, int max_wgs) {
-  const bool split_bf16 = kind != 0;
+  const bool split_bf16 = kind == 1 || kind == 2;
   // A job's cost per sample tile = its bytes (nf + kf KiB) + a fixed part (barrier, waits, the 4 DMA issues per wave,
   // transposed reads, MFMAs) worth about 128 KiB of streaming: single-job timings fit t = a (nf + kf + c0) with c0 = 24
   // at a full grid, but under load the sweep over c0 keeps improving up to ~128 and is flat beyond (tools/sweep_dw.py).  Split the sample range of every job in proportion.
@@ -1883,8 +1887,8 @@ static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, co
   // the partial-tile slots live behind the dZ fragment blocks in the caller's dz workspace (nerf_mlp_dz_bytes counts them)
   d.partial = reinterpret_cast<float*>(static_cast<char*>(dz) + padded_tiles(ntiles * 32) * zstride * 16) + (size_t)slot_base * DW_SLOT_FLOATS;
   int rc;
-  if (kind == 2) {             // 16 x 16-fragment jobs, one wave per SIMD (mlp_s16w.hip); same slots and reduce
-    rc = s16::launch_dw_wide_kernel(d, nw, s);
+  if (kind >= 2) {             // 16 x 16-fragment jobs, one wave per SIMD (mlp_dww.hip); same slots and reduce
+    rc = launch_dw_wide_kernel(d, nw, kind == 2, s);
   } else if (kind == 1) {      // hi + lo fragment blocks, three MFMAs per product (mlp_s16.hip); same jobs, slots and reduce
     rc = s16::launch_dw_kernel(d, nw, s);
   } else {
@@ -1906,12 +1910,10 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
     hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * nparams, s);
     if (e != hipSuccess) return fail(NERF_E_HIP, "nerf_mlp_backward: memset: %s", hipGetErrorString(e));
   }
-  if (!split_bf16)
-    return launch_dw_part(d, nj, ntiles, nparams, acts, dz, astride, zstride, grads, s, 0, a_lo, z_lo, 0, DW_MAX_WGS);
-  if (s16::g_dw_variant == 0)
-    return launch_dw_part(d, nj, ntiles, nparams, acts, dz, astride, zstride, grads, s, 1, a_lo, z_lo, 0, DW_MAX_WGS);
-  // "dw22_variant" 1 (default): the 256 x 256 jobs on the one-wave-per-SIMD kernel, the others on the 16-wave kernel; two launches, each with
-  // its own static split over all CUs and its own half of the partial-tile slots
+  // "dw22_variant" / "dw16_variant" 1 (default): the 256 x 256 jobs on the one-wave-per-SIMD kernel, the others on the 16-wave kernel;
+  // two launches, each with its own static split over all CUs and its own half of the partial-tile slots.  0: one 16-wave launch.
+  if ((split_bf16 ? s16::g_dw_variant : g_dw16_variant) == 0)
+    return launch_dw_part(d, nj, ntiles, nparams, acts, dz, astride, zstride, grads, s, split_bf16 ? 1 : 0, a_lo, z_lo, 0, DW_MAX_WGS);
   DwArgs wide = d, rest = d;
   int nwide = 0, nrest = 0;
   for (int j = 0; j < nj; ++j) {
@@ -1920,11 +1922,11 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
   }
   const int half = DW_MAX_WGS / 2;
   if (nwide) {
-    const int rc = launch_dw_part(wide, nwide, ntiles, nparams, acts, dz, astride, zstride, grads, s, 2, a_lo, z_lo, half, half);
+    const int rc = launch_dw_part(wide, nwide, ntiles, nparams, acts, dz, astride, zstride, grads, s, split_bf16 ? 2 : 3, a_lo, z_lo, half, half);
     if (rc) return rc;
   }
   if (nrest) {
-    const int rc = launch_dw_part(rest, nrest, ntiles, nparams, acts, dz, astride, zstride, grads, s, 1, a_lo, z_lo, 0, half);
+    const int rc = launch_dw_part(rest, nrest, ntiles, nparams, acts, dz, astride, zstride, grads, s, split_bf16 ? 1 : 0, a_lo, z_lo, 0, half);
     if (rc) return rc;
   }
   return NERF_OK;

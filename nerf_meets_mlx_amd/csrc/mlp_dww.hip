@@ -1,42 +1,47 @@
-// Split-bf16 weight gradients of the 256 x 256 jobs (dZ [256] x H [256] fragments, hi + lo blocks) with ONE wave per SIMD.
+// Weight gradients of the 256 x 256 jobs (dZ [256] x H [256]: 16 x 16 fragments) with ONE wave per SIMD, for the split-bf16 stores
+// (hi + lo blocks, three MFMAs per product: precision 22) and for the bf16 stores (precision 16).
 //
 // Reference: the adjoint of models/NeRF.py:201-243 under nn.value_and_grad (entrypoints/__test_nerf.py:240-293); same job table,
-// stage layout (mlp_s16.hip: 16 samples of every operand fragment as 1 KiB pair blocks, filled by LDS-DMA, read back with
-// ds_read_b64_tr_b16), partial-tile slots and reduce kernel as s16_dw_kernel.  What differs is who computes what:
+// pair-block stages (mlp_s16.hip: the operand fragments of a stage as 1 KiB pair blocks, filled by LDS-DMA, read back with
+// ds_read_b64_tr_b16), partial-tile slots and reduce kernel as the 16-wave kernels.  What differs is who computes what:
 //
-//   s16_dw_kernel (16 waves, 128 registers each): a wave owns 2 x 2 output tiles and cannot hold a second operand set, so every
-//   stage is  barrier -> transposed reads -> wait -> MFMAs  with the 4 waves of a SIMD in lock-step behind the stage barrier:
-//   measured (tools/probe_dw22_chain.py, timing-only builds) 0.78 us of MFMA time per stage grow to 1.1 us without any DMA and
-//   to 1.46 us with the loads, against 1.25 us for the loads alone.
+//   16 waves (s16_dw_kernel / mlp_dw_kernel, 128 registers per wave): a wave owns 2 x 2 output tiles and cannot hold a second
+//   operand set, so every stage is  barrier -> transposed reads -> wait -> MFMAs  with the 4 waves of a SIMD in lock-step behind
+//   the stage barrier: measured for the split form (tools/probe_dw22_chain.py, timing-only builds) 0.78 us of MFMA time per stage
+//   grow to 1.1 us without any DMA and to 1.46 us with the loads, against 1.25 us for the loads alone.
 //
 //   here (4 waves, 512 registers each): a wave owns 4 x 4 output tiles (256 accumulator registers), keeps TWO operand sets
 //   (2 x 64 registers) and reads the operands of stage j + 1 between the MFMAs of stage j; three stages stay in flight behind the
 //   one being read.  Per stage and CU the LDS delivers 64 KiB instead of 128 (a tile is read by 2 waves, not 4), and everything
-//   that is not an MFMA (32 transposed reads, 8 DMAs, 16 v_dot2c for the bias sums per wave) is spread over the 48 MFMA issue
-//   gaps of the stage in eight slices (sched_barrier between them), where it is nearly free (MI355X_MICROARCH.md, "price of a
-//   filler beside MFMAs").  The stage barrier sits behind the first slice: a wave brings six MFMAs with it into the wait.
+//   that is not an MFMA (32 transposed reads, 8 DMAs, 16 v_dot2c for the bias sums per wave) is spread over the MFMA issue gaps
+//   of the stage in eight slices (sched_barrier between them), where it is nearly free (MI355X_MICROARCH.md, "price of a filler
+//   beside MFMAs").  The stage barrier sits behind the first slice: a wave brings its first MFMAs with it into the wait.
+//   Measured (split form, 786 k samples): a 256 x 256 job alone 272 against 305 us, the eight of them 2.08 ms = 6.2 TB/s.
+//
+// A stage is 32 KiB in both forms: SPLIT 16 samples x (dZ hi | dZ lo | H hi | H lo) x 8 pair blocks, 48 MFMAs per wave
+// (lo hi + hi lo + hi hi); bf16 32 samples x (dZ first half | dZ second half | H first half | H second half) x 8 pair blocks,
+// 32 MFMAs per wave (one per k-step) -- the block a lo part occupies in the one is the second 16 samples in the other.
 //
 // Bias gradient: row sums of dZ.  Each wave reads its four dZ tiles in an order rotated by its column (local tile i = tile
 // 4 wr + ((i + 2 wc) & 3)) and sums the rows of its local tiles 0 and 1: the two waves of a row cover the row's four tiles with
 // the SAME instruction stream (no branch, no select).
 //
-// Jobs that are not 256 x 256 keep s16_dw_kernel (a 4 x 4-tile wave would multiply zeros for them); mlp.hip launches the two
-// kernels one after the other, each over its own static split of all CUs.
+// Jobs that are not 256 x 256 keep the 16-wave kernels (a 4 x 4-tile wave would multiply zeros for them); mlp.hip launches the
+// two kernels one after the other, each over its own static split of all CUs.
 #include "mlp_s16_dev.h"
-#include "mlp_s16.h"
 
 #ifndef NERF_DWX
 #define NERF_DWX 0            // timing-only builds (bit mask): 1 no DMAs, 2 no transposed reads, 4 no stage barrier, 8 no bias sums, 16 no MFMAs
 #endif
 
 namespace nerf {
-namespace s16 {
+using s16::mfma32;
 
 constexpr int DWW_STAGES = 4, DWW_STAGE_BYTES = 32 * 1024, DWW_LDS_BYTES = DWW_STAGES * DWW_STAGE_BYTES;
 constexpr int DWW_WAVES = 4, DWW_DPW = 8;                  // 32 pair blocks per stage: 8 DMAs per wave
-constexpr int DWW_SLICES = 8, DWW_MPS = 6;                 // 48 MFMAs per stage and wave = 8 slices of 6
+constexpr int DWW_SLICES = 8;                              // the MFMAs of a stage and wave (48 split, 32 bf16) in 8 slices
 
-struct WOps { bf16x8 ah[4], al[4], bh[4], bl[4]; };        // dZ tiles (hi, lo), H tiles (hi, lo): 64 registers
+struct WOps { bf16x8 ah[4], al[4], bh[4], bl[4]; };        // dZ tiles (hi, lo | samples 0-15, 16-31), H tiles likewise: 64 registers
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
 __device__ __forceinline__ bf16x8 trw(unsigned addr) {     // per-lane LDS byte address of the operand's first half
@@ -60,11 +65,13 @@ __device__ __forceinline__ void dma_block_nt(const char* gbase_uniform, unsigned
 
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
-__global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
+template <bool SPLIT>
+__global__ void __launch_bounds__(64 * DWW_WAVES) mlp_dww_kernel(DwArgs a) {
+  constexpr int MPS = SPLIT ? 6 : 4;                       // MFMAs per slice
   char* smem = ring_smem;
   int bj = blockIdx.x, job_id = 0;
   while (bj >= a.splits[job_id]) { bj -= a.splits[job_id]; ++job_id; }
-  const DwJob jb = a.jobs[job_id];                         // nf == kf == 16 (launch_dw_wide checks)
+  const DwJob jb = a.jobs[job_id];                         // nf == kf == 16 (mlp.hip:launch_dw)
   const int tile_lo = (int)((int64_t)a.ntiles * bj / a.splits[job_id]);
   const int tile_hi = (int)((int64_t)a.ntiles * (bj + 1) / a.splits[job_id]);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,8 +99,9 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
 #pragma unroll
   for (int k = 0; k < DWW_DPW; ++k) {
     const int j = wv + 4 * (k & 3), lo_part = j >> 3, t = j & 7;
-    const int slot = (k < 4 ? jb.dz_slot + lo_part * a.z_lo : jb.act_slot + lo_part * a.a_lo) + 2 * t + src_sel;
-    lane_off[k] = (unsigned)(slot * 1024 + 32 * src_row + 16 * src_half);
+    // blocks 8..15 of an operand: SPLIT the lo blocks (z_lo / a_lo slots further), bf16 samples 16..31 of the same fragments
+    const int slot = (k < 4 ? jb.dz_slot + (SPLIT ? lo_part * a.z_lo : 0) : jb.act_slot + (SPLIT ? lo_part * a.a_lo : 0)) + 2 * t + src_sel;
+    lane_off[k] = (unsigned)(slot * 1024 + 32 * src_row + 16 * src_half + (SPLIT ? 0 : 512 * lo_part));
   }
   const char* dzb = reinterpret_cast<const char*>(a.dz);
   const char* acb = reinterpret_cast<const char*>(a.acts);
@@ -101,11 +109,12 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
   unsigned ldsw = lds0 + wv * 1024;
   asm volatile("" : "+s"(zstride_b), "+s"(astride_b), "+s"(dzb), "+s"(acb), "+s"(ldsw));
 
-  const int ht_lo = 2 * tile_lo, n = 2 * (tile_hi - tile_lo);     // stages of this workgroup (even)
-  auto issue_k = [&](int ht, int slot, int k) {            // DMA k of stage ht (absolute half-tile index) into ring slot `slot`
+  // stages of this workgroup: SPLIT half tiles (two per sample tile), bf16 sample tiles
+  const int ht_lo = SPLIT ? 2 * tile_lo : tile_lo, n = SPLIT ? 2 * (tile_hi - tile_lo) : tile_hi - tile_lo;
+  auto issue_k = [&](int ht, int slot, int k) {            // DMA k of stage ht (absolute stage index) into ring slot `slot`
 #if !(NERF_DWX & 1)
-    const long long tile = ht >> 1;
-    const char* base = (k < 4 ? dzb + tile * zstride_b : acb + tile * astride_b) + 512 * (ht & 1);
+    const long long tile = SPLIT ? ht >> 1 : ht;
+    const char* base = (k < 4 ? dzb + tile * zstride_b : acb + tile * astride_b) + (SPLIT ? 512 * (ht & 1) : 0);
     dma_block_nt(base, lane_off[k], ldsw + slot * DWW_STAGE_BYTES + k * 4096);
 #endif
   };
@@ -118,9 +127,14 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
   auto mfma_m = [&](const WOps& o, int m) {                // MFMA m of a stage: product type m / 16, tile (i, k) = (m % 16) / 4, m % 4
 #if !(NERF_DWX & 16)
     const int pt = m >> 4, i = (m >> 2) & 3, k = m & 3;
-    if (pt == 0) acc[i][k] = mfma32(o.al[i], o.bh[k], acc[i][k]);
-    else if (pt == 1) acc[i][k] = mfma32(o.ah[i], o.bl[k], acc[i][k]);
-    else acc[i][k] = mfma32(o.ah[i], o.bh[k], acc[i][k]);
+    if (SPLIT) {                                           // lo hi + hi lo + hi hi
+      if (pt == 0) acc[i][k] = mfma32(o.al[i], o.bh[k], acc[i][k]);
+      else if (pt == 1) acc[i][k] = mfma32(o.ah[i], o.bl[k], acc[i][k]);
+      else acc[i][k] = mfma32(o.ah[i], o.bh[k], acc[i][k]);
+    } else {                                               // samples 0-15, then 16-31
+      if (pt == 0) acc[i][k] = mfma32(o.ah[i], o.bh[k], acc[i][k]);
+      else acc[i][k] = mfma32(o.al[i], o.bl[k], acc[i][k]);
+    }
 #else
     asm volatile("" :: "v"(o.al[m & 3]), "v"(o.ah[m & 3]), "v"(o.bh[m & 3]), "v"(o.bl[m & 3]));
 #endif
@@ -146,7 +160,7 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
     // the previous step's reads as pending and waiting for THIS step's reads in front of this step's MFMAs)
     __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
 #pragma unroll
-    for (int m = 0; m < DWW_MPS; ++m) mfma_m(use, m);
+    for (int m = 0; m < MPS; ++m) mfma_m(use, m);
     dot_d(use, 0); dot_d(use, 1);
     __builtin_amdgcn_sched_barrier(0);
     // stage j + 1 has landed (this wave's DMAs: the stages issued behind it may stay in flight) ...
@@ -172,7 +186,7 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
         for (int r = RD0[s]; r < RD0[s + 1]; ++r) read_tile(ld, r, so);
       }
 #pragma unroll
-      for (int m = DWW_MPS * s; m < DWW_MPS * (s + 1); ++m) mfma_m(use, m);
+      for (int m = MPS * s; m < MPS * (s + 1); ++m) mfma_m(use, m);
       dot_d(use, 2 * s); dot_d(use, 2 * s + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -197,9 +211,9 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
     step(x, y, j, j & 3, BoolC<true>());
     step(y, x, j + 1, (j + 1) & 3, BoolC<true>());
   }
-  for (; j < n; j += 2) {                                  // the last stages (n is even)
+  for (; j < n; j += 2) {                                  // the last stages
     step(x, y, j, j & 3, BoolC<false>());
-    step(y, x, j + 1, (j + 1) & 3, BoolC<false>());
+    if (j + 1 < n) step(y, x, j + 1, (j + 1) & 3, BoolC<false>());
   }
 
   const int rr = lane & 31, hh = lane >> 5;
@@ -224,17 +238,18 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) s16_dww_kernel(DwArgs a) {
   }
 }
 
-int launch_dw_wide_kernel(const DwArgs& d, int workgroups, hipStream_t s) {
-  static bool done[64] = {};
+int launch_dw_wide_kernel(const DwArgs& d, int workgroups, bool split_bf16, hipStream_t s) {
+  static bool done[2][64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!done[dev]) {
-    done[dev] = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dww_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DWW_LDS_BYTES);
+  const void* k = split_bf16 ? reinterpret_cast<const void*>(mlp_dww_kernel<true>) : reinterpret_cast<const void*>(mlp_dww_kernel<false>);
+  if (!done[split_bf16][dev]) {
+    done[split_bf16][dev] = true;
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DWW_LDS_BYTES);
   }
-  hipLaunchKernelGGL(s16_dww_kernel, dim3(workgroups), dim3(64 * DWW_WAVES), DWW_LDS_BYTES, s, d);
-  return check_launch("mlp dW (split bf16, 256 x 256 jobs)");
+  if (split_bf16) hipLaunchKernelGGL(mlp_dww_kernel<true>, dim3(workgroups), dim3(64 * DWW_WAVES), DWW_LDS_BYTES, s, d);
+  else hipLaunchKernelGGL(mlp_dww_kernel<false>, dim3(workgroups), dim3(64 * DWW_WAVES), DWW_LDS_BYTES, s, d);
+  return check_launch(split_bf16 ? "mlp dW (split bf16, 256 x 256 jobs)" : "mlp dW (bf16, 256 x 256 jobs)");
 }
 
-}  // namespace s16
 }  // namespace nerf

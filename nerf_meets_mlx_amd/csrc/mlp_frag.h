@@ -223,5 +223,7 @@ struct DwArgs {
 constexpr int DW_SLOT_FLOATS = 64 * 1024 + 256;
 constexpr int DW_MAX_WGS = 512;
 constexpr int64_t DW_PARTIAL_BYTES = (int64_t)DW_MAX_WGS * DW_SLOT_FLOATS * 4;
+// dW of jobs of 16 x 16 fragments only, one wave per SIMD (mlp_dww.hip); split_bf16: hi + lo blocks (precision 22), else bf16 blocks
+int launch_dw_wide_kernel(const DwArgs& d, int workgroups, bool split_bf16, hipStream_t s);
 
 }  // namespace nerf

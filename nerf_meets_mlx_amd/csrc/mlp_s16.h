@@ -33,9 +33,7 @@ int backward_chain(const void* packed_s16, const void* acts, const float* d_raw,
                    int64_t zstride16, int persistent_wgs, hipStream_t s);
 // the weight-gradient kernel proper (job table, split and partial slots prepared by mlp.hip's launch_dw)
 int launch_dw_kernel(const DwArgs& d, int workgroups, hipStream_t s);
-// the same for jobs of 16 x 16 fragments only, one wave per SIMD (mlp_s16w.hip)
-int launch_dw_wide_kernel(const DwArgs& d, int workgroups, hipStream_t s);
-extern int g_dw_variant;      // A/B knob ("dw22_variant"): 1 = 256 x 256 jobs on the one-wave-per-SIMD kernel, the others on the 16-wave kernel (default); 0 = every job on the 16-wave kernel
+extern int g_dw_variant;      // A/B knob ("dw22_variant"): 1 = 256 x 256 jobs on the one-wave-per-SIMD kernel (mlp_dww.hip), the others on the 16-wave kernel (default); 0 = every job on the 16-wave kernel
 
 }  // namespace s16
 }  // namespace nerf

@@ -339,7 +339,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
 // ------------------------------------------------------------------------------------------
 // the general dW kernel: 16 waves (4 x 4 waves of 2 x 2 output tiles), any job shape
 // ------------------------------------------------------------------------------------------
-// Since round 5 the 256 x 256 jobs run on mlp_s16w.hip's one-wave-per-SIMD kernel; this one takes the narrow jobs (input layers,
+// Since round 5 the 256 x 256 jobs run on mlp_dww.hip's one-wave-per-SIMD kernel; this one takes the narrow jobs (input layers,
 // heads, the 2 x 64 model) and, with nerf_set_option("dw22_variant", 0), every job.
 //  * Ring: a stage takes npairs KiB, the ring all 160 KiB of the CU: 5 stages for a 256 x 256 job, up to 8 for the narrow ones.
 //    ONE barrier per sample tile (two stages): the pair is waited for, the barrier frees the slots of the pair before it, every
@@ -360,7 +360,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
 // hold a second operand set, so reads and MFMAs of a stage are serial per wave and the four waves of a SIMD, in step behind the
 // barrier, overlap them only by drifting apart.  An 8-wave form with two operand sets (round 5, removed) measured 3.54-3.72:
 // two waves per SIMD in step leave the matrix pipe idle while both run their DMA / address / read instructions.  The 4-wave form
-// (mlp_s16w.hip) is what hides them.
+// (mlp_dww.hip) is what hides them.
 #ifndef NERF_DW_RING_CAP
 #define NERF_DW_RING_CAP 8
 #endif
@@ -589,7 +589,7 @@ int backward_chain(const void* packed_s16, const void* acts, const float* d_raw,
   return check_launch("mlp backward chain (split bf16)");
 }
 
-int g_dw_variant = 1;          // nerf_set_option("dw22_variant"): 1 (default) 256 x 256 jobs on mlp_s16w.hip's kernel, the others here; 0 every job here
+int g_dw_variant = 1;          // nerf_set_option("dw22_variant"): 1 (default) 256 x 256 jobs on mlp_dww.hip's kernel, the others here; 0 every job here
 
 int launch_dw_kernel(const DwArgs& d, int workgroups, hipStream_t s) {
   static DevOnce once;

@@ -6,7 +6,9 @@ sys.path.insert(0, ".")
 from nerf_meets_mlx_amd import _native
 from nerf_meets_mlx_amd.models.NeRF import NeRF
 dev="cuda"
-m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0, precision=22)
+prec = int(sys.argv[1]) if len(sys.argv) > 1 else 22          # 22: split-bf16 stores ("dw22_variant"); 16: bf16 stores ("dw16_variant")
+key = b"dw22_variant" if prec == 22 else b"dw16_variant"
+m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=dev, seed=0, precision=prec)
 g=torch.Generator().manual_seed(0)
 B,n=4096,192
 o=torch.nn.functional.normalize(torch.randn(B,3,generator=g),dim=-1)*4; d=-o/4+0.25*torch.randn(B,3,generator=g)
@@ -15,7 +17,7 @@ z=torch.sort(torch.rand(B,n,generator=g)*4+2,-1).values.to(dev); dr=(torch.randn
 opt=lambda k,v: _native.check(_native.lib().nerf_set_option(k,v))
 ref = None
 for variant in (0, 1, 0, 1):
-    opt(b"dw22_variant", variant)
+    opt(key, variant)
     opt(b"bwd_stage", 0)
     m.query(rays,z,train=True); g_ = m.backward(dr).clone()
     if ref is None: ref = g_
@@ -29,4 +31,4 @@ for variant in (0, 1, 0, 1):
         for _ in range(10): m.backward(dr)
         e1.record(); torch.cuda.synchronize()
         print(f"variant {variant} {name}: {e0.elapsed_time(e1)/10:.3f} ms" + (f"   gradient vs variant 0: bit-equal {same}, rel-L2 {rel:.1e}" if stage == 2 else ""), flush=True)
-opt(b"bwd_stage",0); opt(b"dw22_variant", 1)
+opt(b"bwd_stage",0); opt(key, 1)

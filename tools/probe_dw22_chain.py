@@ -1,4 +1,4 @@
-"""dW (split bf16) timing probe for the NERF_DWX timing-only builds (tools/ab_one.sh dwxN mlp_s16 -DNERF_DWX=N, or mlp_s16w): all
+"""dW (split bf16) timing probe for the NERF_DWX timing-only builds (tools/ab_one.sh dwxN mlp_s16 -DNERF_DWX=N, or mlp_dww): all
 jobs, and ONE job alone on 256 workgroups (256 x 256: 192 stages each; 256 x 64; alpha), for "dw22_variant" 1 (256 x 256 jobs on the
 one-wave-per-SIMD kernel) and 0 (every job on the 16-wave kernel)."""
 import os, sys, torch
