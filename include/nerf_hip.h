@@ -347,6 +347,7 @@ int nerf_comm_destroy(void* comm);
  *   "dw_workgroups"   0 auto (one per CU) | workgroups of the weight-gradient kernel
  *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (negative = automatic, the
  *                     default: 128 for the bf16 kernel, 32 for the split-bf16 kernels)
+ *   "dw_ring_cap"     most stages the LDS ring of the 16-wave split-bf16 weight-gradient kernel may hold (default 8; 2 .. 16)
  *   "dw16_variant"    bf16 weight gradients: as "dw22_variant" (1 default | 0 every job on the 16-wave kernel)
  *   "dw22_variant"    split-bf16 weight gradients: 1 (default) the 256 x 256 jobs on the one-wave-per-SIMD kernel (4 x 4 output tiles
  *                     per wave, two operand register sets), the other jobs on the 16-wave kernel -- two launches | 0 every job on the

@@ -341,7 +341,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
 // ------------------------------------------------------------------------------------------
 // Since round 5 the 256 x 256 jobs run on mlp_dww.hip's one-wave-per-SIMD kernel; this one takes the narrow jobs (input layers,
 // heads, the 2 x 64 model) and, with nerf_set_option("dw22_variant", 0), every job.
-//  * Ring: a stage takes npairs KiB, the ring all 160 KiB of the CU: 5 stages for a 256 x 256 job, up to 8 for the narrow ones.
+//  * Ring: a stage takes npairs KiB, the ring all 160 KiB of the CU: 5 stages for a 256 x 256 job, up to 8 for the narrow ones ("dw_ring_cap"; 6 / 8 / 16 measure the same in the training step).
 //    ONE barrier per sample tile (two stages): the pair is waited for, the barrier frees the slots of the pair before it, every
 //    stage whose slot is free is issued (two in steady state; ns - 2 stages stay in flight while a pair is processed), then both
 //    half tiles are processed back to back -- the fixed cost of a stage boundary (barrier skew, the refill DMAs' blocked issue,
@@ -361,10 +361,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
 // barrier, overlap them only by drifting apart.  An 8-wave form with two operand sets (round 5, removed) measured 3.54-3.72:
 // two waves per SIMD in step leave the matrix pipe idle while both run their DMA / address / read instructions.  The 4-wave form
 // (mlp_dww.hip) is what hides them.
-#ifndef NERF_DW_RING_CAP
-#define NERF_DW_RING_CAP 8
-#endif
-constexpr int DW_LDS_BYTES = 160 * 1024, DW_MAX_STAGES = NERF_DW_RING_CAP;
+constexpr int DW_LDS_BYTES = 160 * 1024;                  // the ring holds min(DW_LDS_BYTES / stage bytes, DwArgs.ring_cap) stages
 
 __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   char* smem = ring_smem;
@@ -382,7 +379,7 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   const bool active = (wr * DW_NPW < n_tiles) && (wc * 2 < k_tiles);
   const int kc = (k_tiles + 1) >> 1;                      // active wave columns (1, 2 or 4)
   int stride = npairs * 1024, ns = DW_LDS_BYTES / stride;
-  if (ns > DW_MAX_STAGES) ns = DW_MAX_STAGES;
+  if (ns > a.ring_cap) ns = a.ring_cap;
   const int cnt_w = (wv < npairs ? 1 : 0) + (wv + DW_WAVES < npairs ? 1 : 0);   // this wave's DMAs per stage
   f32x16 acc[DW_NPW][2];
 #pragma unroll
@@ -471,20 +468,15 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
       }
     }
   };
-  // wait until this wave's DMAs of everything but the `younger` most recently issued stages have landed (wave-uniform, <= 6 stages
+  // wait until this wave's DMAs of everything but the `younger` most recently issued stages have landed (wave-uniform, <= 14 stages
   // x <= 2 DMAs), and until its own transposed reads of the previous pair are complete
   auto wait_landed = [&](int younger) {
     switch (younger * cnt_w) {
-      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+#define NERF_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
+      NERF_VM_CASE(0) NERF_VM_CASE(1) NERF_VM_CASE(2) NERF_VM_CASE(3) NERF_VM_CASE(4) NERF_VM_CASE(5) NERF_VM_CASE(6) NERF_VM_CASE(7)
+      NERF_VM_CASE(8) NERF_VM_CASE(9) NERF_VM_CASE(10) NERF_VM_CASE(11) NERF_VM_CASE(12) NERF_VM_CASE(13) NERF_VM_CASE(14)
+      NERF_VM_CASE(16) NERF_VM_CASE(18) NERF_VM_CASE(20) NERF_VM_CASE(22) NERF_VM_CASE(24) NERF_VM_CASE(26) NERF_VM_CASE(28)
+#undef NERF_VM_CASE
       default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
     }
   };
