@@ -296,3 +296,56 @@ def test_drop_in_surface_defaults_to_the_reference_tolerance():
     with pytest.raises(ValueError):                      # the 2 x 64 model has no fp32-MFMA kernels: refused, never a fallback
         NeRF(n_layers=2, width_layers=64, channel_input=32, channel_input_views=16, list_skip_connection_layers=[],
              is_use_view_directions=True, device=DEV, seed=0, precision=32).packed()
+
+
+@pytest.mark.parametrize("kind,precision", [("view", 22), ("view", 16), ("image", 22), ("image", 16), ("small", 22)])
+@pytest.mark.parametrize("M", [1, 32, 97, 5 * 32, 37 * 32 + 5, 8192 + 33])
+def test_weight_gradients_of_the_two_dw_launch_forms_agree(kind, precision, M):
+    """"dw22_variant" / "dw16_variant" 1 (default): the 256 x 256 jobs on the one-wave-per-SIMD kernel (csrc/mlp_dww.hip: its own
+    prologue / steady state / tail split, odd stage counts for the bf16 stores, sample counts of one ragged tile), the other jobs
+    on the 16-wave kernel, two launches over disjoint partial-tile slots; 0: every job on the 16-wave kernel.  The two forms sum a
+    tile's products in different orders: equal to float32 rounding of a sum (<= 1e-5 rel-L2 per tensor), each bit-reproducible.
+    The 2 x 64 model has no 256 x 256 job: there the two settings must be bit-equal."""
+    from nerf_meets_mlx_amd import _native
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    gen = torch.Generator().manual_seed(100 + M)
+    if kind == "view":
+        arch = O.NerfArch()
+        m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=0, precision=precision)
+        flat = O.flatten_params(arch, O.init_params(arch, 0)) * 1.5
+        m.load_flat(flat)
+        x, g = torch.randn(M, 90, generator=gen), torch.randn(M, 4, generator=gen)
+    elif kind == "image":
+        m, arch, flat = _image_pair(precision)
+        x, g = torch.randn(M, 40, generator=gen), torch.randn(M, 3, generator=gen)
+    else:
+        m, arch, flat = _small_pair(precision)
+        x, g = torch.randn(M, 48, generator=gen), torch.randn(M, 4, generator=gen)
+    key = b"dw22_variant" if precision == 22 else b"dw16_variant"
+    lib = _native.lib()
+    got = {}
+    try:
+        for v in (0, 1, 1):
+            _native.check(lib.nerf_set_option(key, v))
+            m.grads.fill_(float("nan"))
+            m.forward(x.to(DEV), train=True)
+            gr = m.backward(g.to(DEV)).cpu().clone()
+            assert torch.isfinite(gr).all()
+            if v in got:
+                assert torch.equal(got[v], gr), "not bit-reproducible"
+            got[v] = gr
+    finally:
+        _native.check(lib.nerf_set_option(key, 1))
+    if kind == "small":
+        assert torch.equal(got[0], got[1])
+        return
+    off, worst = 0, 0.0
+    for name, o_, i_ in arch.layer_shapes():
+        for cnt in (o_ * i_, o_):
+            a, b = got[1][off:off + cnt], got[0][off:off + cnt]
+            if float(b.norm()) > 0:
+                worst = max(worst, _rel_l2(a, b))
+            else:
+                assert float(a.norm()) == 0
+            off += cnt
+    assert worst < 1e-5, worst
