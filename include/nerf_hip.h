@@ -347,6 +347,9 @@ int nerf_comm_destroy(void* comm);
  *   "dw_workgroups"   0 auto (one per CU) | workgroups of the weight-gradient kernel
  *   "dw_unit_bias"    fixed per-tile cost of a dW job, in KiB-of-streaming units, for its static split (negative = automatic, the
  *                     default: 128 for the bf16 kernel, 32 for the split-bf16 kernels)
+ *   "dw_private_tiles" split-bf16 weight-gradient jobs of at most this many 32 x 32 output tiles (default 4 = the most; 0 = none) run as
+ *                     sixteen independent wave pipelines (no workgroup barrier; fixed-order tree sum at the end) instead of the shared
+ *                     4 x 4 wave grid, of which such a job occupies one wave.  Sums in a different order: ~1e-6 rel-L2, bit-reproducible
  *   "dw_ring_cap"     most stages the LDS ring of the 16-wave split-bf16 weight-gradient kernel may hold (default 8; 2 .. 16)
  *   "dw16_variant"    bf16 weight gradients: as "dw22_variant" (1 default | 0 every job on the 16-wave kernel)
  *   "dw22_variant"    split-bf16 weight gradients: 1 (default) the 256 x 256 jobs on the one-wave-per-SIMD kernel (4 x 4 output tiles

@@ -1481,6 +1481,7 @@ static int g_dw_bias = -1;     // per-tile fixed cost of a dW job in fragment un
                                // closely: tools/sweep_dw22_bias.py, 3.30-3.34 ms at 16-48 against 3.47 at 128)
 static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW only (on whatever dz holds)
 static int g_dw_ring_cap = 8;  // "dw_ring_cap": most stages the 16-wave split-bf16 dW kernel's LDS ring may hold (2 .. 16)
+static int g_dw_private = 4;   // "dw_private_tiles": split-bf16 dW jobs of at most this many output tiles run as sixteen wave-private pipelines (0 = off)
 static int g_dw16_variant = 1;  // "dw16_variant": bf16 weight gradients, 1 = 256 x 256 jobs on mlp_dww.hip's kernel (default), 0 = every job on mlp_dw_kernel
 static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
@@ -1582,6 +1583,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "ngp_ray_major")) { g_ngp_ray_major = value ? 1 : 0; return NERF_OK; }
   if (!strcmp(key, "dw22_variant")) { s16::g_dw_variant = value == 0 ? 0 : 1; return NERF_OK; }
   if (!strcmp(key, "dw16_variant")) { g_dw16_variant = value == 0 ? 0 : 1; return NERF_OK; }
+  if (!strcmp(key, "dw_private_tiles")) { g_dw_private = value < 0 ? 0 : value > 4 ? 4 : value; return NERF_OK; }
   if (!strcmp(key, "dw_ring_cap")) { g_dw_ring_cap = value < 2 ? 2 : value > 16 ? 16 : value; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
@@ -1885,7 +1887,7 @@ static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, co
   NERF_REQUIRE(slot_base + nw <= DW_MAX_WGS, NERF_E_SHAPE, "nerf_mlp_backward: dw_workgroups must be <= %d", DW_MAX_WGS);
   d.ntiles = (int)ntiles; d.astride = astride; d.zstride = zstride;
   d.acts = acts; d.dz = dz; d.grads = grads;
-  d.a_lo = a_lo; d.z_lo = z_lo; d.ring_cap = g_dw_ring_cap;
+  d.a_lo = a_lo; d.z_lo = z_lo; d.ring_cap = g_dw_ring_cap; d.private_max_tiles = g_dw_private;
   // the partial-tile slots live behind the dZ fragment blocks in the caller's dz workspace (nerf_mlp_dz_bytes counts them)
   d.partial = reinterpret_cast<float*>(static_cast<char*>(dz) + padded_tiles(ntiles * 32) * zstride * 16) + (size_t)slot_base * DW_SLOT_FLOATS;
   int rc;

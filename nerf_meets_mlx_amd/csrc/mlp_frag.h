@@ -214,6 +214,7 @@ struct DwArgs {
   float* grads;
   float* partial;         // [workgroup][DW_SLOT_FLOATS] split-K partial tiles (deterministic two-stage reduction)
   int ring_cap;           // s16_dw_kernel: most stages its LDS ring may hold (<= 16)
+  int private_max_tiles;  // s16_dw_kernel: jobs of at most this many output tiles (<= 4) run as sixteen independent wave pipelines; 0 = none
   int a_lo, z_lo;         // split-bf16 stores (mlp_s16.hip's dW kernel): slot distance from a hi block to its lo block in acts / dz
 };
 // One slot per dW workgroup: up to 8 x 8 output tiles of 32 x 32 floats (tile (nt, kt) at (8 nt + kt) * 1024, row-major

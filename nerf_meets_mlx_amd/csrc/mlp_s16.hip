@@ -363,6 +363,135 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* blk, int hq, int fsel, int
 // (mlp_dww.hip) is what hides them.
 constexpr int DW_LDS_BYTES = 160 * 1024;                  // the ring holds min(DW_LDS_BYTES / stage bytes, DwArgs.ring_cap) stages
 
+// Jobs whose whole output is at most four tiles (the 2 x 64 model's layers, the view model's dir0 | dirPE and rgb jobs): with the
+// 4 x 4 wave grid of 2 x 2 tiles ONE wave (or two) of sixteen has work, and the workgroup's rate is that wave's serial chain
+// barrier -> reads -> wait -> MFMAs (measured: the 2 x 64 model's dW at 2.2 TB/s).  Here every wave is a pipeline of its own:
+// wave w takes the stages w, w + 16, ... of the workgroup's sample range, moves them through its own 10 KiB of the LDS with its own
+// DMAs and its own vmcnt wait -- no barrier in the loop, sixteen stages in flight per CU -- and accumulates its own copy of the
+// NT x KT tiles; the sixteen copies are added through the LDS in a fixed binary tree at the end (bit-reproducible).
+constexpr int DWP_WAVE_BYTES = 10 * 1024;
+template <int NT, int KT>
+__device__ __forceinline__ void dw_private(const DwArgs& a, const DwJob& jb, int tile_lo, int tile_hi, char* smem, int wv, int lane) {
+  constexpr int NP = 2 * (NT + KT);                        // pair blocks per stage: dZ hi [NT] | dZ lo [NT] | H hi [KT] | H lo [KT]
+  static_assert(NP * 1024 <= DWP_WAVE_BYTES && NT * KT <= 4, "wave-private dW: one stage per wave, at most four tiles");
+  f32x16 acc[NT][KT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][k][e] = 0.0f;
+  float bsum[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) bsum[i] = 0.0f;
+  const int g16 = lane >> 4, i16 = lane & 15, hq = g16 >> 1, fsel = g16 & 1;
+  char* mine = smem + wv * DWP_WAVE_BYTES;
+  const unsigned lds_mine = __builtin_amdgcn_readfirstlane(lds_addr_of(mine));
+  const int src_row = lane >> 2, src_sel = (lane >> 1) & 1, src_half = lane & 1;
+  const char* dzb = reinterpret_cast<const char*>(a.dz);
+  const char* acb = reinterpret_cast<const char*>(a.acts);
+  long long zstride_b = a.zstride * 16, astride_b = a.astride * 16;
+  int z_lo = a.z_lo, a_lo = a.a_lo, dz_slot = jb.dz_slot, act_slot = jb.act_slot, nf = jb.nf, kf = jb.kf;
+  asm volatile("" : "+s"(zstride_b), "+s"(astride_b), "+s"(z_lo), "+s"(a_lo), "+s"(dz_slot), "+s"(act_slot), "+s"(nf), "+s"(kf));
+  const int ht_hi = 2 * tile_hi;
+  for (int ht = 2 * tile_lo + wv; ht < ht_hi; ht += DW_WAVES) {
+    // this wave's transposed reads of its previous stage are complete (every one feeds an MFMA above; the wait makes it explicit)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(NERF_DWX & 1)
+    const int64_t tile = ht >> 1;
+    const unsigned row_off = (unsigned)(32 * (16 * (ht & 1) + src_row) + 16 * src_half);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool is_z = i < 2 * NT;
+      const int j = is_z ? i : i - 2 * NT, nt_ = is_z ? NT : KT;
+      const int lo_part = j >= nt_ ? 1 : 0, t = lo_part ? j - nt_ : j;
+      const int nfr = is_z ? nf : kf;
+      int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;          // odd counts: rows past n_valid, never read back
+      const int slot = (is_z ? dz_slot + lo_part * z_lo : act_slot + lo_part * a_lo) + fr;
+      dma_frag_nt((is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)slot * 1024 + row_off, lds_mine + i * 1024);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8 bh[KT], bl[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      bh[k] = tr_pair(mine + (2 * NT + k) * 1024, hq, fsel, i16);
+      bl[k] = tr_pair(mine + (2 * NT + KT + k) * 1024, hq, fsel, i16);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const bf16x8 ah = tr_pair(mine + i * 1024, hq, fsel, i16);
+      const bf16x8 al = tr_pair(mine + (NT + i) * 1024, hq, fsel, i16);
+#if !(NERF_DWX & 8)
+      const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const bf16x2 ph = {ah[j], ah[j + 1]}, pl = {al[j], al[j + 1]};
+        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pl, ones, bsum[i], false);
+        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(ph, ones, bsum[i], false);
+      }
+#endif
+#if NERF_DWX & 16
+      asm volatile("" :: "v"(ah), "v"(al), "v"(bh[0]), "v"(bl[0]));
+#else
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        acc[i][k] = mfma32(al, bh[k], acc[i][k]);
+        acc[i][k] = mfma32(ah, bl[k], acc[i][k]);
+        acc[i][k] = mfma32(ah, bh[k], acc[i][k]);
+      }
+#endif
+    }
+  }
+  // sixteen copies -> one, through the LDS: waves [h, 2h) hand theirs to waves [0, h), h = 8, 4, 2, 1 (fixed order)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  float* xl = reinterpret_cast<float*>(smem);              // [giver][tile | bias row][register][lane]: 4 KiB per tile, 256 B per bias row
+  constexpr int GIVER_FLOATS = (NT * KT * 16 + NT) * 64;
+#pragma unroll 1
+  for (int h = DW_WAVES / 2; h >= 1; h >>= 1) {
+    __builtin_amdgcn_s_barrier();                          // the loop's reads (first round) / the previous round's reads are done
+    if (wv >= h && wv < 2 * h) {
+      float* dst = xl + (size_t)(wv - h) * GIVER_FLOATS + lane;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[((i * KT + k) * 16 + e) * 64] = acc[i][k][e];
+        dst[(NT * KT * 16 + i) * 64] = bsum[i];
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wv < h) {
+      const float* src = xl + (size_t)wv * GIVER_FLOATS + lane;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][k][e] += src[((i * KT + k) * 16 + e) * 64];
+        bsum[i] += src[(NT * KT * 16 + i) * 64];
+      }
+    }
+  }
+  if (wv != 0) return;
+  const int rr = lane & 31, hh = lane >> 5;
+  float* slot = a.partial + (size_t)blockIdx.x * DW_SLOT_FLOATS;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      float* tile = slot + (8 * i + k) * 1024;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32 + rr] = acc[i][k][e];
+    }
+    if (jb.b_off >= 0) {
+      const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // the two sample halves of the k-step
+      if (hh == 0) slot[64 * 1024 + 32 * i + rr] = tot;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   char* smem = ring_smem;
   int bj = blockIdx.x, job_id = 0;
@@ -375,7 +504,20 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   const int n_tiles = (jb.nf + 1) >> 1, k_tiles = (jb.kf + 1) >> 1;
   const bool col_major = k_tiles <= 2;                    // see s16_dw_kernel
   const int wr = col_major ? (wv & 3) : (wv >> 2), wc = col_major ? (wv >> 2) : (wv & 3);
-  const int npairs = 2 * (n_tiles + k_tiles);             // real pair blocks per stage (10 .. 32)
+  const int npairs = 2 * (n_tiles + k_tiles);             // real pair blocks per stage (4 .. 32)
+  if (a.private_max_tiles >= n_tiles * k_tiles && npairs * 1024 <= DWP_WAVE_BYTES) {       // tiny jobs: sixteen independent wave pipelines
+    switch (8 * n_tiles + k_tiles) {
+      case 8 * 1 + 1: dw_private<1, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 1 + 2: dw_private<1, 2>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 1 + 3: dw_private<1, 3>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 1 + 4: dw_private<1, 4>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 2 + 1: dw_private<2, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 2 + 2: dw_private<2, 2>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 3 + 1: dw_private<3, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 4 + 1: dw_private<4, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      default: break;
+    }
+  }
   const bool active = (wr * DW_NPW < n_tiles) && (wc * 2 < k_tiles);
   const int kc = (k_tiles + 1) >> 1;                      // active wave columns (1, 2 or 4)
   int stride = npairs * 1024, ns = DW_LDS_BYTES / stride;
