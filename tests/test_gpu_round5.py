@@ -352,3 +352,30 @@ def test_weight_gradients_of_the_two_dw_launch_forms_agree(kind, precision, M):
                 assert float(a.norm()) == 0
             off += cnt
     assert worst < 1e-5, worst
+
+
+@pytest.mark.parametrize("precision", [22, 16])
+@pytest.mark.parametrize("wgs", [7, 96, 300, 512])
+def test_weight_gradients_do_not_depend_on_the_workgroup_count_beyond_rounding(precision, wgs):
+    """`dw_workgroups` (split-K width of the weight-gradient launches; with the two-launch form each launch is clamped to its half
+    of the partial-tile slots): any setting gives the gradient of the default to float32 summation rounding."""
+    from nerf_meets_mlx_amd import _native
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    lib = _native.lib()
+    arch = O.NerfArch()
+    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=0, precision=precision)
+    m.load_flat(O.flatten_params(arch, O.init_params(arch, 0)) * 1.5)
+    gen = torch.Generator().manual_seed(5)
+    M = 3000 * 32 + 17
+    x, g = torch.randn(M, 90, generator=gen).to(DEV), torch.randn(M, 4, generator=gen).to(DEV)
+    m.forward(x, train=True)
+    ref = m.backward(g).cpu().clone()
+    try:
+        _native.check(lib.nerf_set_option(b"dw_workgroups", wgs))
+        m.grads.fill_(float("nan"))
+        m.forward(x, train=True)
+        got = m.backward(g).cpu()
+    finally:
+        _native.check(lib.nerf_set_option(b"dw_workgroups", 0))
+    assert torch.isfinite(got).all()
+    assert _rel_l2(got, ref) < 1e-5
