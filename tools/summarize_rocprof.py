@@ -35,7 +35,7 @@ DYNAMIC_LDS = {
     "mlp32_fwd_kernel": 4 * 256 * 32 * 4, "mlp32_bwd_kernel": 4 * 256 * 32 * 4,     # one 32 KiB slab per wave
     "mlp22_fwd_kernel": 4 * 32 * 1024 + 2560 * 4,             # split-fp16 render forward: the same ring
     "s16_fwd_kernel": 4 * 32 * 1024 + 2560 * 4, "s16_bwd_kernel": 4 * 32 * 1024 + 2560 * 4,   # split-bf16 training: the same ring
-    "s16_dww_kernel": 4 * 32 * 1024,                          # 256 x 256 jobs: 4 stages x 32 pair blocks of 1 KiB
+    "mlp_dww_kernel": 4 * 32 * 1024,                          # 256 x 256 jobs: 4 stages x 32 pair blocks of 1 KiB
     "s16_dw_kernel": 160 * 1024,                              # the other jobs: a ring over the whole LDS of the CU
 }
 
