@@ -66,8 +66,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_world_size_n_gloo(world):
+    """world 2, and a rehearsal of the eight ranks of the driver's SCALE run: shard arithmetic, distinct per-rank streams, the summed
+    and scaled gradient equals the full-batch gradient, identical Adam steps, the image gather."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
