@@ -351,7 +351,9 @@ int nerf_comm_destroy(void* comm);
  *                     sixteen independent wave pipelines (no workgroup barrier; fixed-order tree sum at the end) instead of the shared
  *                     4 x 4 wave grid, of which such a job occupies one wave.  Sums in a different order: ~1e-6 rel-L2, bit-reproducible
  *   "dw_ring_cap"     most stages the LDS ring of the 16-wave split-bf16 weight-gradient kernel may hold (default 8; 2 .. 16)
- *   "dw16_variant"    bf16 weight gradients: as "dw22_variant" (1 default | 0 every job on the 16-wave kernel)
+ *   "dw16_variant"    bf16 weight gradients: 1 (default) the 256 x 256 jobs on the one-wave-per-SIMD kernel, job lists of tiny jobs (the
+ *                     2 x 64 model) on the split kernels' 16-wave kernel (wave-private pipelines), the other jobs on round 2's 16-wave
+ *                     kernel | 0 every job on round 2's kernel | 2, 3: A/B forms of 1 (round 2's / round 5's kernel for every narrow job)
  *   "dw22_variant"    split-bf16 weight gradients: 1 (default) the 256 x 256 jobs on the one-wave-per-SIMD kernel (4 x 4 output tiles
  *                     per wave, two operand register sets), the other jobs on the 16-wave kernel -- two launches | 0 every job on the
  *                     16-wave kernel.  The two sum a tile's products and a bias row in different orders: gradients agree to ~1e-6

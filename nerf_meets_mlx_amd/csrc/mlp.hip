@@ -1482,7 +1482,7 @@ static int g_dw_bias = -1;     // per-tile fixed cost of a dW job in fragment un
 static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW only (on whatever dz holds)
 static int g_dw_ring_cap = 8;  // "dw_ring_cap": most stages the 16-wave split-bf16 dW kernel's LDS ring may hold (2 .. 16)
 static int g_dw_private = 4;   // "dw_private_tiles": split-bf16 dW jobs of at most this many output tiles run as sixteen wave-private pipelines (0 = off)
-static int g_dw16_variant = 1;  // "dw16_variant": bf16 weight gradients, 1 = 256 x 256 jobs on mlp_dww.hip's kernel (default), 0 = every job on mlp_dw_kernel
+static int g_dw16_variant = 1;  // "dw16_variant": bf16 weight gradients: 1 (default) = 256 x 256 jobs on mlp_dww.hip's kernel, tiny-job lists on mlp_s16.hip's, the rest on mlp_dw_kernel; 0 = every job on mlp_dw_kernel; 2 = as 1 without the tiny-job rule; 3 = as 1 with mlp_s16.hip's kernel for every narrow job
 static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
 static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
@@ -1582,7 +1582,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "hash_combine_max_res")) { g_hash_combine_max_res = value > 0 ? value : 0; return NERF_OK; }
   if (!strcmp(key, "ngp_ray_major")) { g_ngp_ray_major = value ? 1 : 0; return NERF_OK; }
   if (!strcmp(key, "dw22_variant")) { s16::g_dw_variant = value == 0 ? 0 : 1; return NERF_OK; }
-  if (!strcmp(key, "dw16_variant")) { g_dw16_variant = value == 0 ? 0 : 1; return NERF_OK; }
+  if (!strcmp(key, "dw16_variant")) { g_dw16_variant = value < 0 ? 0 : value > 3 ? 3 : value; return NERF_OK; }
   if (!strcmp(key, "dw_private_tiles")) { g_dw_private = value < 0 ? 0 : value > 4 ? 4 : value; return NERF_OK; }
   if (!strcmp(key, "dw_ring_cap")) { g_dw_ring_cap = value < 2 ? 2 : value > 16 ? 16 : value; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
@@ -1885,6 +1885,8 @@ static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, co
     d.splits[big] -= 1; nw -= 1;
   }
   NERF_REQUIRE(slot_base + nw <= DW_MAX_WGS, NERF_E_SHAPE, "nerf_mlp_backward: dw_workgroups must be <= %d", DW_MAX_WGS);
+  bool all_tiny = true;
+  for (int j = 0; j < nj; ++j) all_tiny = all_tiny && ((d.jobs[j].nf + 1) / 2) * ((d.jobs[j].kf + 1) / 2) <= 4;
   d.ntiles = (int)ntiles; d.astride = astride; d.zstride = zstride;
   d.acts = acts; d.dz = dz; d.grads = grads;
   d.a_lo = a_lo; d.z_lo = z_lo; d.ring_cap = g_dw_ring_cap; d.private_max_tiles = g_dw_private;
@@ -1894,7 +1896,12 @@ static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, co
   if (kind >= 2) {             // 16 x 16-fragment jobs, one wave per SIMD (mlp_dww.hip); same slots and reduce
     rc = launch_dw_wide_kernel(d, nw, kind == 2, s);
   } else if (kind == 1) {      // hi + lo fragment blocks, three MFMAs per product (mlp_s16.hip); same jobs, slots and reduce
-    rc = s16::launch_dw_kernel(d, nw, s);
+    rc = s16::launch_dw_kernel(d, nw, true, s);
+  } else if (g_dw16_variant == 3 || (g_dw16_variant == 1 && all_tiny)) {
+    // the 16-wave kernel of mlp_s16.hip over the bf16 stores: for job lists of tiny jobs only (the 2 x 64 model: sixteen wave-private
+    // pipelines, configs[4] bf16 training 3.10 -> 3.21 M rays/s).  For the view model's narrow jobs it measures like round 2's
+    // mlp_dw_kernel below (4.45 against 4.43 ms per training step), which keeps them ("dw16_variant" 3 forces this kernel).
+    rc = s16::launch_dw_kernel(d, nw, false, s);
   } else {
     static DevOnce lds_attr_set;
     if (lds_attr_set.first())

@@ -32,7 +32,7 @@ int forward(const void* packed_s16, const float* bias_slots, const float* x, con
 int backward_chain(const void* packed_s16, const void* acts, const float* d_raw, int64_t M, void* dz, int64_t astride16,
                    int64_t zstride16, int persistent_wgs, hipStream_t s);
 // the weight-gradient kernel proper (job table, split and partial slots prepared by mlp.hip's launch_dw)
-int launch_dw_kernel(const DwArgs& d, int workgroups, hipStream_t s);
+int launch_dw_kernel(const DwArgs& d, int workgroups, bool split_bf16, hipStream_t s);     // split_bf16: hi + lo blocks; else the bf16 stores
 extern int g_dw_variant;      // A/B knob ("dw22_variant"): 1 = 256 x 256 jobs on the one-wave-per-SIMD kernel (mlp_dww.hip), the others on the 16-wave kernel (default); 0 = every job on the 16-wave kernel
 
 }  // namespace s16

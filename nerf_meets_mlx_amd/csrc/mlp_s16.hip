@@ -370,7 +370,7 @@ constexpr int DW_LDS_BYTES = 160 * 1024;                  // the ring holds min(
 // DMAs and its own vmcnt wait -- no barrier in the loop, sixteen stages in flight per CU -- and accumulates its own copy of the
 // NT x KT tiles; the sixteen copies are added through the LDS in a fixed binary tree at the end (bit-reproducible).
 constexpr int DWP_WAVE_BYTES = 10 * 1024;
-template <int NT, int KT>
+template <int NT, int KT, bool SPLIT>
 __device__ __forceinline__ void dw_private(const DwArgs& a, const DwJob& jb, int tile_lo, int tile_hi, char* smem, int wv, int lane) {
   constexpr int NP = 2 * (NT + KT);                        // pair blocks per stage: dZ hi [NT] | dZ lo [NT] | H hi [KT] | H lo [KT]
   static_assert(NP * 1024 <= DWP_WAVE_BYTES && NT * KT <= 4, "wave-private dW: one stage per wave, at most four tiles");
@@ -393,13 +393,15 @@ __device__ __forceinline__ void dw_private(const DwArgs& a, const DwJob& jb, int
   long long zstride_b = a.zstride * 16, astride_b = a.astride * 16;
   int z_lo = a.z_lo, a_lo = a.a_lo, dz_slot = jb.dz_slot, act_slot = jb.act_slot, nf = jb.nf, kf = jb.kf;
   asm volatile("" : "+s"(zstride_b), "+s"(astride_b), "+s"(z_lo), "+s"(a_lo), "+s"(dz_slot), "+s"(act_slot), "+s"(nf), "+s"(kf));
-  const int ht_hi = 2 * tile_hi;
-  for (int ht = 2 * tile_lo + wv; ht < ht_hi; ht += DW_WAVES) {
+  // stages: SPLIT half tiles (two per sample tile: 16 samples of hi + lo blocks), bf16 whole sample tiles (samples 0-15 | 16-31 in
+  // the blocks the lo parts occupy in the split form)
+  const int ht_hi = SPLIT ? 2 * tile_hi : tile_hi;
+  for (int ht = (SPLIT ? 2 * tile_lo : tile_lo) + wv; ht < ht_hi; ht += DW_WAVES) {
     // this wave's transposed reads of its previous stage are complete (every one feeds an MFMA above; the wait makes it explicit)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if !(NERF_DWX & 1)
-    const int64_t tile = ht >> 1;
-    const unsigned row_off = (unsigned)(32 * (16 * (ht & 1) + src_row) + 16 * src_half);
+    const int64_t tile = SPLIT ? ht >> 1 : ht;
+    const unsigned row_off0 = (unsigned)(32 * ((SPLIT ? 16 * (ht & 1) : 0) + src_row) + 16 * src_half);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const bool is_z = i < 2 * NT;
@@ -407,7 +409,8 @@ __device__ __forceinline__ void dw_private(const DwArgs& a, const DwJob& jb, int
       const int lo_part = j >= nt_ ? 1 : 0, t = lo_part ? j - nt_ : j;
       const int nfr = is_z ? nf : kf;
       int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;          // odd counts: rows past n_valid, never read back
-      const int slot = (is_z ? dz_slot + lo_part * z_lo : act_slot + lo_part * a_lo) + fr;
+      const int slot = (is_z ? dz_slot + (SPLIT ? lo_part * z_lo : 0) : act_slot + (SPLIT ? lo_part * a_lo : 0)) + fr;
+      const unsigned row_off = row_off0 + (SPLIT ? 0 : 512 * lo_part);
       dma_frag_nt((is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)slot * 1024 + row_off, lds_mine + i * 1024);
     }
 #endif
@@ -436,9 +439,14 @@ __device__ __forceinline__ void dw_private(const DwArgs& a, const DwJob& jb, int
 #else
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
-        acc[i][k] = mfma32(al, bh[k], acc[i][k]);
-        acc[i][k] = mfma32(ah, bl[k], acc[i][k]);
-        acc[i][k] = mfma32(ah, bh[k], acc[i][k]);
+        if (SPLIT) {
+          acc[i][k] = mfma32(al, bh[k], acc[i][k]);
+          acc[i][k] = mfma32(ah, bl[k], acc[i][k]);
+          acc[i][k] = mfma32(ah, bh[k], acc[i][k]);
+        } else {
+          acc[i][k] = mfma32(ah, bh[k], acc[i][k]);
+          acc[i][k] = mfma32(al, bl[k], acc[i][k]);
+        }
       }
 #endif
     }
@@ -492,6 +500,7 @@ __device__ __forceinline__ void dw_private(const DwArgs& a, const DwJob& jb, int
   }
 }
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   char* smem = ring_smem;
   int bj = blockIdx.x, job_id = 0;
@@ -507,14 +516,14 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
   const int npairs = 2 * (n_tiles + k_tiles);             // real pair blocks per stage (4 .. 32)
   if (a.private_max_tiles >= n_tiles * k_tiles && npairs * 1024 <= DWP_WAVE_BYTES) {       // tiny jobs: sixteen independent wave pipelines
     switch (8 * n_tiles + k_tiles) {
-      case 8 * 1 + 1: dw_private<1, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
-      case 8 * 1 + 2: dw_private<1, 2>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
-      case 8 * 1 + 3: dw_private<1, 3>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
-      case 8 * 1 + 4: dw_private<1, 4>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
-      case 8 * 2 + 1: dw_private<2, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
-      case 8 * 2 + 2: dw_private<2, 2>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
-      case 8 * 3 + 1: dw_private<3, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
-      case 8 * 4 + 1: dw_private<4, 1>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 1 + 1: dw_private<1, 1, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 1 + 2: dw_private<1, 2, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 1 + 3: dw_private<1, 3, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 1 + 4: dw_private<1, 4, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 2 + 1: dw_private<2, 1, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 2 + 2: dw_private<2, 2, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 3 + 1: dw_private<3, 1, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
+      case 8 * 4 + 1: dw_private<4, 1, SPLIT>(a, jb, tile_lo, tile_hi, smem, wv, lane); return;
       default: break;
     }
   }
@@ -549,8 +558,8 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
     return;
 #endif
     const unsigned st = lds0 + __builtin_amdgcn_readfirstlane(slot) * stride;
-    const int64_t tile = ht >> 1;
-    const unsigned row_off = (unsigned)(32 * (16 * (ht & 1) + src_row) + 16 * src_half);
+    const int64_t tile = SPLIT ? ht >> 1 : ht;
+    const unsigned row_off0 = (unsigned)(32 * ((SPLIT ? 16 * (ht & 1) : 0) + src_row) + 16 * src_half);
 #pragma unroll
     for (int k = 0; k < DW_NPW; ++k) {
       const int i = wv + DW_WAVES * k;                     // wave-uniform
@@ -562,7 +571,9 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
         const int t = lo_part ? j - nt_ : j;
         const int nfr = is_z ? nf : kf;
         int fr = 2 * t + src_sel; if (fr >= nfr) fr = nfr - 1;
-        const int slot_ = (is_z ? dz_slot + lo_part * z_lo : act_slot + lo_part * a_lo) + fr;
+        // part 1 of an operand: SPLIT the lo blocks (z_lo / a_lo slots further), bf16 samples 16..31 of the same fragments
+        const int slot_ = (is_z ? dz_slot + (SPLIT ? lo_part * z_lo : 0) : act_slot + (SPLIT ? lo_part * a_lo : 0)) + fr;
+        const unsigned row_off = row_off0 + (SPLIT ? 0 : 512 * lo_part);
         const char* src = (is_z ? dzb + tile * zstride_b : acb + tile * astride_b) + (int64_t)slot_ * 1024 + row_off;
         dma_frag_nt(src, st + i * 1024);
       }
@@ -602,9 +613,14 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
 #else
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          acc[i][k] = mfma32(al, bh[k], acc[i][k]);
-          acc[i][k] = mfma32(ah, bl[k], acc[i][k]);
-          acc[i][k] = mfma32(ah, bh[k], acc[i][k]);
+          if (SPLIT) {                         // lo hi + hi lo + hi hi
+            acc[i][k] = mfma32(al, bh[k], acc[i][k]);
+            acc[i][k] = mfma32(ah, bl[k], acc[i][k]);
+            acc[i][k] = mfma32(ah, bh[k], acc[i][k]);
+          } else {                             // samples 0-15, then 16-31
+            acc[i][k] = mfma32(ah, bh[k], acc[i][k]);
+            acc[i][k] = mfma32(al, bl[k], acc[i][k]);
+          }
         }
 #endif
       }
@@ -622,17 +638,18 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
       default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
     }
   };
-  const int ht_lo = 2 * tile_lo, n = 2 * (tile_hi - tile_lo);   // stages of this workgroup (even: two per sample tile)
+  // stages of this workgroup: SPLIT half tiles (two per sample tile, n even), bf16 sample tiles (n may be odd: the last pair is single)
+  const int ht_lo = SPLIT ? 2 * tile_lo : tile_lo, n = SPLIT ? 2 * (tile_hi - tile_lo) : tile_hi - tile_lo;
   int issued = 0, slot_i = 0, slot_p = 0;                  // stages issued so far; the slot the next issue / the next process uses
   for (; issued < ns && issued < n; ++issued) { issue(ht_lo + issued, slot_i); slot_i = slot_i + 1 == ns ? 0 : slot_i + 1; }
   for (int p = 0; p < n; p += 2) {
-    wait_landed(issued - (p + 2));                         // stages p, p + 1 landed (this wave's part)
+    wait_landed(issued - (p + 2 < n ? p + 2 : n));         // stages p, p + 1 landed (this wave's part)
     DW_BARRIER();                                          // ... for every wave; every wave is done with the stages before p
 #pragma unroll
     for (int k = 0; k < 2; ++k)                            // the slots of stages < p are free: stage s may go once s - ns < p
       if (issued < n && issued - ns < p) { issue(ht_lo + issued, slot_i); slot_i = slot_i + 1 == ns ? 0 : slot_i + 1; ++issued; }
     process(smem + slot_p * stride); slot_p = slot_p + 1 == ns ? 0 : slot_p + 1;
-    process(smem + slot_p * stride); slot_p = slot_p + 1 == ns ? 0 : slot_p + 1;
+    if (SPLIT || p + 1 < n) { process(smem + slot_p * stride); slot_p = slot_p + 1 == ns ? 0 : slot_p + 1; }
   }
   // bias partial sums of a wave row -> its wc == 0 wave, through the LDS (every wave takes part in the two barriers)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -725,12 +742,14 @@ int backward_chain(const void* packed_s16, const void* acts, const float* d_raw,
 
 int g_dw_variant = 1;          // nerf_set_option("dw22_variant"): 1 (default) 256 x 256 jobs on mlp_dww.hip's kernel, the others here; 0 every job here
 
-int launch_dw_kernel(const DwArgs& d, int workgroups, hipStream_t s) {
-  static DevOnce once;
-  if (once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
-  hipLaunchKernelGGL(s16_dw_kernel, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
-  return check_launch("mlp dW (split bf16)");
+int launch_dw_kernel(const DwArgs& d, int workgroups, bool split_bf16, hipStream_t s) {
+  static DevOnce once[2];
+  if (once[split_bf16].first())
+    (void)hipFuncSetAttribute(split_bf16 ? reinterpret_cast<const void*>(s16_dw_kernel<true>) : reinterpret_cast<const void*>(s16_dw_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+  if (split_bf16) hipLaunchKernelGGL(s16_dw_kernel<true>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
+  else hipLaunchKernelGGL(s16_dw_kernel<false>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
+  return check_launch(split_bf16 ? "mlp dW (split bf16)" : "mlp dW (bf16)");
 }
 
 }  // namespace s16
