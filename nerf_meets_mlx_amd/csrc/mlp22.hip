@@ -172,6 +172,9 @@ __device__ __forceinline__ void pe22_row(const float* __restrict__ row, int g, u
 // one linear layer on register-resident (hi, lo) activations
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+#if NERF_ABLATE == 41 || NERF_ABLATE == 42      // timing-only builds: 41 the ring protocol alone (DMAs, waits, barriers); 42 the same + the LDS weight reads
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
@@ -187,6 +190,9 @@ __device__ __forceinline__ void layer22(WS& ws, int pbase, int bias_slot, const 
   // (~60 VALU instructions) leaves the matrix pipe idle for its whole length -- there is no second wave to fill it.
   auto piece = [&](int nt, int pcs, f32x4 (&m)[2], f32x4 (&c)[2]) {
     const int s = pcs >> 1, i = 2 * (pcs & 1);
+#if NERF_ABLATE == 41 || NERF_ABLATE == 42
+    return;
+#endif
 #if NERF_F22_PIN
     if (pcs == 0) {
 #pragma unroll

@@ -198,9 +198,11 @@ struct RingW {
       issue_one((fn / CHUNK + STAGES - 1) % NCHUNK, (ring_pos + STAGES - 1) & (STAGES - 1),
                 (fn % CHUNK) / (CHUNK / DPW));
 #endif
+#if NERF_ABLATE != 41         // timing-only build 41 (with the MFMAs and epilogues of mlp22.hip compiled out): the ring protocol alone
 #pragma unroll
     for (int i = 0; i < RING_GROUP; ++i)
       nxt[i] = *reinterpret_cast<const bf16x8*>(ring_smem + woff + ((fn + i) % CHUNK) * 1024);
+#endif
   }
   __device__ __forceinline__ void note_stores(int) {}
   __device__ __forceinline__ void new_pass() {
