@@ -56,7 +56,31 @@ struct PairSink {
     store_frag(base, tile, stride16, slot0 + idx, vh, r, h);
     store_frag(base, tile, stride16, slot0 + lo_off + idx, vl, r, h);
   }
+  __device__ __forceinline__ void put1(int idx, bool lo, const bf16x8& v) const {       // one block: the hi or the lo part of fragment idx
+    store_frag(base, tile, stride16, slot0 + (lo ? lo_off : 0) + idx, v, r, h);
+  }
 };
+// The four 1 KiB stores of a finished output tile (fragments 2 t, 2 t + 1, hi and lo) go out ONE per k-step behind the tile's last
+// epilogue quarter instead of all four at once: one wave per SIMD, and a wave issuing a store issues nothing else for ~29 cycles, of
+// which the MFMA in front of it covers 24 -- a burst of four leaves the matrix pipe idle for three of them (round 5; the ISA of
+// round 4's kernels: 50 MFMA gaps with four stores, 16 with three, 16 with one; now 118 with one, 68 with two).  Worth little:
+// chain 2.39 -> 2.37 ms per 786 k samples, forward unchanged, the training step -0.4 % (A/B with -DNERF_S16_SPREAD_STORES=0): most of
+// what the stores cost (22 % of each chain) is not their issue pattern.  Store s of tile t is due at flattened k-step
+// (t + 1) KS + quarter_pos(KS, 3) + s of the layer; what falls behind the layer's last k-step goes out in its tail.
+#ifndef NERF_S16_SPREAD_STORES
+#define NERF_S16_SPREAD_STORES 1
+#endif
+template <class SINK>
+__device__ __forceinline__ void put_due(const SINK& sink, int KS, int g, int tiles, const bf16x8* oh, const bf16x8* ol) {
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int d = g - quarter_pos(KS, 3) - s4;               // = (t + 1) KS for the tile t whose store s4 is due now
+    if (d >= KS && d % KS == 0 && d / KS - 1 < tiles) {
+      const int f = 2 * (d / KS - 1) + (s4 >> 1);
+      sink.put1(f, (s4 & 1) != 0, (s4 & 1) ? ol[f] : oh[f]);
+    }
+  }
+}
 
 // Epilogue of one accumulator tile in four quarters (issued between the MFMAs of the NEXT n-tile: one wave per SIMD, nothing
 // else fills the matrix pipe while a wave does vector work).  f0 / f1: the two 16-feature fragments of the 32-row tile.
@@ -111,9 +135,10 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
         for (int q = 0; q < 4; ++q)
           if (quarter_pos(KS, q) == ks) {
             finish_quarter<RELU, MASKOUT>(prev, q, nt - 1, oh[2 * nt - 2], oh[2 * nt - 1], ol[2 * nt - 2], ol[2 * nt - 1], mask);
-            if (q == 3) { sink.put(2 * nt - 2, oh[2 * nt - 2], ol[2 * nt - 2]); sink.put(2 * nt - 1, oh[2 * nt - 1], ol[2 * nt - 1]); }
+            if (q == 3 && !NERF_S16_SPREAD_STORES) { sink.put(2 * nt - 2, oh[2 * nt - 2], ol[2 * nt - 2]); sink.put(2 * nt - 1, oh[2 * nt - 1], ol[2 * nt - 1]); }
           }
       }
+      if (NERF_S16_SPREAD_STORES) put_due(sink, KS, nt * KS + ks, NT - 1, oh, ol);
     }
     prev = acc;
   }
@@ -123,6 +148,10 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     finish_quarter<RELU, MASKOUT>(prev, q, NT - 1, oh[2 * NT - 2], oh[2 * NT - 1], ol[2 * NT - 2], ol[2 * NT - 1], mask);
+  if (NERF_S16_SPREAD_STORES) {                            // stores of tiles < NT - 1 that were due behind the last k-step
+#pragma unroll
+    for (int g = NT * KS; g < NT * KS + quarter_pos(KS, 3) + 4; ++g) put_due(sink, KS, g, NT - 1, oh, ol);
+  }
   sink.put(2 * NT - 2, oh[2 * NT - 2], ol[2 * NT - 2]);
   sink.put(2 * NT - 1, oh[2 * NT - 1], ol[2 * NT - 1]);
 }
@@ -146,6 +175,7 @@ __device__ __forceinline__ f32x16 head(WS& ws, int fbase, int bias_slot, const b
 // inference: finished fragment pairs go nowhere but the next layer
 struct NoPairSink {
   __device__ __forceinline__ void put(int, const bf16x8&, const bf16x8&) const {}
+  __device__ __forceinline__ void put1(int, bool, const bf16x8&) const {}
 };
 
 // ------------------------------------------------------------------------------------------
@@ -206,15 +236,20 @@ __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&ih)[
         for (int q = 0; q < 4; ++q)
           if (quarter_pos(NS, q) == ns) {
             finish_quarter_bwd<MASK>(prev, q, kt - 1, oh[2 * kt - 2], oh[2 * kt - 1], ol[2 * kt - 2], ol[2 * kt - 1], mask);
-            if (q == 3) { sink.put(2 * kt - 2, oh[2 * kt - 2], ol[2 * kt - 2]); sink.put(2 * kt - 1, oh[2 * kt - 1], ol[2 * kt - 1]); }
+            if (q == 3 && !NERF_S16_SPREAD_STORES) { sink.put(2 * kt - 2, oh[2 * kt - 2], ol[2 * kt - 2]); sink.put(2 * kt - 1, oh[2 * kt - 1], ol[2 * kt - 1]); }
           }
       }
+      if (NERF_S16_SPREAD_STORES) put_due(sink, NS, kt * NS + ns, KT - 1, oh, ol);
     }
     prev = acc;
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     finish_quarter_bwd<MASK>(prev, q, KT - 1, oh[2 * KT - 2], oh[2 * KT - 1], ol[2 * KT - 2], ol[2 * KT - 1], mask);
+  if (NERF_S16_SPREAD_STORES) {
+#pragma unroll
+    for (int g = KT * NS; g < KT * NS + quarter_pos(NS, 3) + 4; ++g) put_due(sink, NS, g, KT - 1, oh, ol);
+  }
   sink.put(2 * KT - 2, oh[2 * KT - 2], ol[2 * KT - 2]);
   sink.put(2 * KT - 1, oh[2 * KT - 1], ol[2 * KT - 1]);
 }
