@@ -452,6 +452,9 @@ __device__ __forceinline__ bf16x8 pe16_dir(const Pe16& q, const float (&x)[3]) {
   return k;
 }
 
+#ifndef NERF_BF16_IGLP
+#define NERF_BF16_IGLP 0      // __builtin_amdgcn_iglp_opt strategy of the bf16 render layers (as in mlp22.hip: 4.79 -> 4.71 ms per fine pass); -1: none
+#endif
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // out[s][nt>>1] (elements 4 (nt&1) + i) = act( W[16-row tile nt] . in[s] + bias ), s = 0..NS-1 sample tiles of 16.
 // hook(nt * KS + ks) runs behind the MFMAs of k-step (nt, ks): a place to put independent VALU work (the NEXT pass's
@@ -461,6 +464,9 @@ __device__ __forceinline__ void layer_fwd16(WS& ws, int fbase, int bias_slot, co
                                             bf16x8 (&out)[NS][NT / 2], int lane, const HOOK& hook = HOOK()) {
   const int g = lane >> 4;
   f32x4 prev[NS];
+#if NERF_BF16_IGLP >= 0
+  __builtin_amdgcn_iglp_opt(NERF_BF16_IGLP);
+#endif
   // epilogue of a finished tile, run under the next tile's MFMAs.  The empty asm pins it there: without it hipcc
   // reads the accumulators right behind their last MFMA (s_nop 6 in both waves of the SIMD at once).  ReLU after
   // the bf16 rounding, as a packed 16-bit integer max on the bit patterns: one VALU op per two values.

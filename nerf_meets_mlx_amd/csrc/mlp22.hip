@@ -30,6 +30,9 @@
 #ifndef NERF_F22_AGPR
 #define NERF_F22_AGPR 1
 #endif
+#ifndef NERF_F22_IGLP
+#define NERF_F22_IGLP 0       // __builtin_amdgcn_iglp_opt strategy of the layer body; -1: none
+#endif
 
 namespace nerf {
 namespace f22 {
@@ -185,6 +188,11 @@ __device__ __forceinline__ void layer22(WS& ws, int pbase, int bias_slot, const 
                                         u32x4 (&oh)[2][NT / 2], u32x4 (&ol)[2][NT / 2], int lane) {
   const int g = lane >> 4;
   f32x4 pm[2], pc[2];
+#if NERF_F22_IGLP >= 0
+  // LLVM's MFMA-interleaving scheduling strategy for this region (the layer is one basic block): the static gap model goes from 0.770
+  // to 0.792 busy (tools/isa_gap_stats.py), measured 15.6-16.1 against 16.1-16.3 ms per fine pass in alternating runs (round 5)
+  __builtin_amdgcn_iglp_opt(NERF_F22_IGLP);
+#endif
   // Epilogue of a finished tile in FOUR pieces (sample tile s = piece >> 1, register pair i = 2 (piece & 1)), issued
   // between the MFMAs of the NEXT tile's k-steps: this kernel runs one wave per SIMD, so an epilogue done in one block
   // (~60 VALU instructions) leaves the matrix pipe idle for its whole length -- there is no second wave to fill it.

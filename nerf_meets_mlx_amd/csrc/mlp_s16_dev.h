@@ -67,6 +67,9 @@ struct PairSink {
 // chain 2.39 -> 2.37 ms per 786 k samples, forward unchanged, the training step -0.4 % (A/B with -DNERF_S16_SPREAD_STORES=0): most of
 // what the stores cost (22 % of each chain) is not their issue pattern.  Store s of tile t is due at flattened k-step
 // (t + 1) KS + quarter_pos(KS, 3) + s of the layer; what falls behind the layer's last k-step goes out in its tail.
+#ifndef NERF_S16_IGLP
+#define NERF_S16_IGLP 0       // __builtin_amdgcn_iglp_opt strategy of the layer bodies (as in mlp22.hip; forward 2.51 -> 2.49, chain 2.40 -> 2.39 ms per 786 k samples); -1: none
+#endif
 #ifndef NERF_S16_SPREAD_STORES
 #define NERF_S16_SPREAD_STORES 1
 #endif
@@ -108,6 +111,9 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
                                           const SINK& sink) {
   const int h = lane >> 5;
   f32x16 prev;
+#if NERF_S16_IGLP >= 0
+  __builtin_amdgcn_iglp_opt(NERF_S16_IGLP);
+#endif
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     f32x16 acc;
@@ -218,6 +224,9 @@ __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&ih)[
                                           bf16x8 (&oh)[2 * KT], bf16x8 (&ol)[2 * KT], const u32x4& mask, int lane,
                                           const SINK& sink) {
   f32x16 prev;
+#if NERF_S16_IGLP >= 0
+  __builtin_amdgcn_iglp_opt(NERF_S16_IGLP);
+#endif
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     f32x16 acc;
