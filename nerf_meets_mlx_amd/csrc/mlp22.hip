@@ -190,7 +190,9 @@ __device__ __forceinline__ void layer22(WS& ws, int pbase, int bias_slot, const 
   f32x4 pm[2], pc[2];
 #if NERF_F22_IGLP >= 0
   // LLVM's MFMA-interleaving scheduling strategy for this region (the layer is one basic block): the static gap model goes from 0.770
-  // to 0.792 busy (tools/isa_gap_stats.py), measured 15.6-16.1 against 16.1-16.3 ms per fine pass in alternating runs (round 5)
+  // to 0.792 busy (tools/isa_gap_stats.py), measured 15.6-16.1 against 16.1-16.3 ms per fine pass in alternating runs (round 5).
+  // (An explicit sched_group_barrier pipeline -- one MFMA, two fillers, per k-step -- reads 0.81 in the same model and measures
+  // SLOWER, 15.95 against 15.82 ms: the model has no latencies.)
   __builtin_amdgcn_iglp_opt(NERF_F22_IGLP);
 #endif
   // Epilogue of a finished tile in FOUR pieces (sample tile s = piece >> 1, register pair i = 2 (piece & 1)), issued
