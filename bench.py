@@ -94,6 +94,12 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # what the communicator is, from inside it (a collective: every rank): backend, ranks that answered an all-reduce, RCCL
+    # version, each rank's device.  A job whose communicator does not hold --gpus ranks never reaches the timed region.
+    args.comm = parallel.comm_info(dev)
+    if args.comm["world_size_seen"] != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the communicator's all-reduce saw {args.comm['world_size_seen']} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
     _native.check(_native.lib().nerf_set_option(b"mlp_variant", args.mlp_variant))
 
     H = W = args.hw
@@ -288,6 +294,11 @@ def main():
                    "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}",
                    "precision": HP},
         "comm_ms_per_step": m["comm_ms_per_step"],
+        # the communicator as the ranks saw it before the timed region (parallel.comm_info) + what the data path sends through it:
+        # one sum all-reduce of the flat float32 gradient buffer per network step (coarse, fine), nothing else
+        "comm": dict(args.comm, allreduce_bytes_per_step=(0 if world == 1 else 595844 * 4 * (2 if NI > 0 else 1)),
+                     collectives_per_step=(0 if world == 1 else (2 if NI > 0 else 1)),
+                     overlap="collectives + Adam on a comm stream; the fine network's run under the next iteration's coarse pass (engine/trainer.py)"),
         # per-rank wall time per step of the timed region (ms_per_step above is their MAX); null at N = 1
         "rank_ms_per_step": (None if m["rank_ms_per_step"] is None else
                              {"min": min(m["rank_ms_per_step"]), "max": max(m["rank_ms_per_step"]), "ranks": m["rank_ms_per_step"]}),
@@ -437,7 +448,9 @@ def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev, precision=None, 
 
     def step():
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        e[0].record(); out = tr.train_step(); e[1].record(); rgb = tr.render_rays(rrays); e[2].record()
+        e[0].record(); out = tr.train_step()
+        tr._join_comm()          # N > 1: the table all-gathers queued on the comm stream belong to the TRAINING phase (stream-side wait)
+        e[1].record(); rgb = tr.render_rays(rrays); e[2].record()
         phase["train"].append((e[0], e[1])); phase["render"].append((e[1], e[2]))
         return out, rgb
 
@@ -479,6 +492,11 @@ def measure_ngp(args, imgs, poses, rposes, K, rank, world, dev, precision=None, 
                    "n_rand_per_gpu": args.n_rand, "render_rays_per_gpu": args.render_rays, "parallelism": f"rays x{world}",
                    "precision": precision},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "ranks": rank_ms},
+        # the communicator as the ranks saw it (parallel.comm_info) + the bytes of the table / MLP gradient exchange per step
+        "comm": dict(getattr(args, "comm", None) or parallel.comm_info(dev),
+                     allreduce_bytes_per_step=(0 if world == 1 else int(tr.field.enc.grad.numel() * tr.field.enc.grad.element_size()
+                                                                        + tr.field.mlp.n_params * 4)),
+                     table_sync=tr.table_sync if world > 1 else None),
         "train_rays_per_s_per_gpu": args.n_rand / t_train, "render_rays_per_s_per_gpu": args.render_rays / t_render,
         "loss_coarse": float(out["loss_coarse"]),
         "roofline": {"bound": "hbm", "kernel": "hashgrid_bwd_combine_kernel<2> (levels 0-4) + hashgrid_bwd_kernel<2, 4> (table gradient scatter, "

@@ -153,9 +153,11 @@ int nerf_hashgrid_backward_rays(const float* rays, const float* z, int64_t B, in
  * all-reduce of their slice of d_tables on another stream), and optionally DETERMINISTIC: fixed_point = 1 makes d_tables
  * an int64 [L,T,F] array of 2^-52 fixed-point accumulators added with integer atomics (associative: the result does not
  * depend on the order the memory side serves the requests; float atomics do).  nerf_adam_step_ex consumes either form.
- * Range of the fixed-point form: an addend with |v| > 256 saturates to +-256, a NaN / Inf addend adds 2^61 units, and
- * nerf_adam_step_ex reads every accumulator outside (-2^60, 2^60) units -- saturated, poisoned, or a per-entry sum beyond
- * +-256, also after a cross-rank sum -- as a NaN gradient: a diverged run surfaces as NaN parameters, as with float atomics. */
+ * Range of the fixed-point form: an addend with |v| > 256 saturates to +-1.5 x 2^60 units (+-384: outside the window below with
+ * 128 to spare, so the ordinary addends of the same entry cannot bring the sum back inside), a NaN / Inf addend adds 2^61
+ * units, and nerf_adam_step_ex reads every accumulator outside (-2^60, 2^60) units -- saturated, poisoned, or a per-entry sum
+ * beyond +-256, also after a cross-rank sum -- as a NaN gradient: a diverged run surfaces as NaN parameters, as with float
+ * atomics.  (Two saturated addends of opposite sign on one entry cancel, like two float gradients of +-1e9 would.) */
 int nerf_hashgrid_backward_ex(const float* x, int64_t M, const float* d_out, int L, int log2_T, int F,
                               const int* resolutions_host, int level_lo, int level_hi, int fixed_point, void* d_tables,
                               void* stream);
@@ -365,8 +367,9 @@ int nerf_comm_destroy(void* comm);
  *                     consecutive depths of one ray.  Same values per sample either way.
  *   "ring_split"      1 (default): one 8-wave workgroup per CU behind a 128 KiB weight ring; 2: two independent 4-wave
  *                     workgroups behind 64 KiB rings (training forward / chain only; measured slower)
- * nerf_get_option returns the current value of "mlp_variant" | "ring_workgroups" | "ring_split" | "dw_workgroups",
- * or -1 for an unknown key.                                                                                        */
+ * nerf_get_option returns the current value of EVERY key nerf_set_option accepts (a get / set pair restores a setting;
+ * "dw_unit_bias" reads -1 while it is automatic), or NERF_OPTION_UNKNOWN for an unknown key.                        */
+#define NERF_OPTION_UNKNOWN (-2147483647 - 1)
 int nerf_set_option(const char* key, int value);
 int nerf_get_option(const char* key);
 

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
+#include <utility>
 
 #include "../../include/nerf_hip.h"
 
@@ -17,6 +19,19 @@ int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// One-time host set-up per DEVICE (the opt-in to dynamic LDS above 64 KiB: hipFuncSetAttribute applies to the device that is
+// current when it is called, and a process may move between devices).  Thread-safe: std::call_once -- a second thread
+// launching the same kernel returns from run() only after the first one's attribute call has completed (a plain bool flag set
+// before / after the call let it launch in between).
+struct DevOnce {
+  std::once_flag flag[64];
+  template <class F> void run(F&& f) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    std::call_once(flag[d], std::forward<F>(f));
+  }
+};
 
 // grid sizing for HBM-bound kernels: enough workgroups to fill 256 CUs, grid-stride the rest
 static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {

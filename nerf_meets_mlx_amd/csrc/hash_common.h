@@ -36,20 +36,23 @@ struct ResTab { float res[32]; };
 #define NERF_HASH_FIX_SHIFT 52
 #define NERF_HASH_FIX_SCALE 4503599627370496.0
 // Representable range and failure behaviour (include/nerf_hip.h, nerf_hashgrid_backward_rays_ex): a finite addend with
-// |v| > 256 saturates to +-2^60 units (= +-256), a NaN / Inf addend adds 2^61 units; nerf_adam_step_ex turns every
+// |v| > 256 saturates to +-(2^60 + 2^59) units -- half a window width OUTSIDE the window, so that the ordinary addends of the same
+// entry (up to +-128 in sum; a coarse-level entry collects hundreds) cannot pull the sum back inside it (round 5 saturated to
+// +-2^60 exactly: -2^60 plus one small positive addend read as a finite -256) --, a NaN / Inf addend adds 2^61 units;
+// nerf_adam_step_ex turns every
 // accumulator outside (-2^60, 2^60) -- a saturated addend, a poisoned one, or a per-entry sum that large, also after the
 // cross-rank all-reduce -- back into a NaN gradient, so that a diverged run surfaces as NaN parameters exactly as it does
 // with float atomics instead of continuing on wrapped integers.  (k poisoned addends on one entry sum to k 2^61 mod 2^64,
 // which is inside the window only for k = 0 mod 8: a diverged batch poisons thousands of entries, 7 of 8 of them stay NaN.)
 #define NERF_HASH_FIX_LIMIT 256.0f
+#define NERF_HASH_FIX_SATURATED ((1ll << 60) + (1ll << 59))
 __device__ __forceinline__ long long nerf_to_fixed(float v) {
   if (!(__builtin_fabsf(v) <= NERF_HASH_FIX_LIMIT))
-    return (v != v || __builtin_isinf(v)) ? (1ll << 61) : (v > 0.0f ? (1ll << 60) : -(1ll << 60));
+    return (v != v || __builtin_isinf(v)) ? (1ll << 61) : (v > 0.0f ? NERF_HASH_FIX_SATURATED : -NERF_HASH_FIX_SATURATED);
   return __double2ll_rn((double)v * NERF_HASH_FIX_SCALE);
 }
 __device__ __forceinline__ bool nerf_fixed_is_poisoned(long long a) {
-  // a outside the OPEN interval (-2^60, 2^60): symmetric, so that a lone negative saturated addend (-2^60 exactly) reads as NaN
-  // like a positive one (round 4 tested [-2^60, 2^60): -256 passed as a finite gradient)
+  // a outside the OPEN interval (-2^60, 2^60), symmetric; saturated addends sit at +-1.5 x 2^60 (above)
   return a <= -(1ll << 60) || a >= (1ll << 60);
 }
 

@@ -201,6 +201,11 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
       }
     }
   }
+  int bad[ST];                      // non-finite inputs of this lane's sample (mlp_frag.h: nonfinite_flags), used at the output store
+#pragma unroll
+  for (int t = 0; t < ST; ++t)
+    bad[t] = nonfinite_flags<32>(nonfinite_bits(pe[t][0]) | nonfinite_bits(pe[t][1]) | nonfinite_bits(pe[t][2]) | nonfinite_bits(pe[t][3]),
+                                 nonfinite_bits(dpe[t][0]) | nonfinite_bits(dpe[t][1]));
 #define store(slot0, t, frags, count) \
   do { if (STORE) { store_frags<count>(a.acts, tile0 + (t), a.astride, slot0, frags, r, h); ws.note_stores(count); } } while (0)
 #pragma unroll
@@ -303,7 +308,7 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
       const int64_t m = (tile0 + t) * 32 + r;
       if (h == 0 && tile0 + t < ntiles && m < a.M) {
         float4 o; o.x = acc[t][0]; o.y = acc[t][1]; o.z = acc[t][2]; o.w = alpha[t];     // [rgb, alpha] raw
-        *reinterpret_cast<float4*>(a.out + m * 4) = o;
+        *reinterpret_cast<float4*>(a.out + m * 4) = poison_raw(o, bad[t]);
       }
     }
   }
@@ -609,6 +614,10 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wt
       }
     }
   };
+  int bad[NS];                      // non-finite inputs of this lane's samples (mlp_frag.h: nonfinite_flags), used at the output store
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    bad[s] = nonfinite_flags<16 | 32>(nonfinite_bits(pe[s][0]) | nonfinite_bits(pe[s][1]), nonfinite_bits(dpe[s][0]));
   bf16x8 ha[NS][8], hb[NS][8];
   layer_fwd16<NS, 2, 16, true>(ws, L16::F_L0, 0, pe, ha, lane);
   layer_fwd16<NS, 8, 16, true>(ws, L16::F_L1 + 0 * 128, 256, ha, hb, lane);
@@ -672,7 +681,7 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wt
       const int64_t m = wtile0 * (16 * NS) + 16 * s + c;
       if (g == 0 && wtile0 < nwtiles && m < a.M) {
         float4 o; o.x = acc[s][0]; o.y = acc[s][1]; o.z = acc[s][2]; o.w = alpha[s];
-        *reinterpret_cast<float4*>(a.out + m * 4) = o;
+        *reinterpret_cast<float4*>(a.out + m * 4) = poison_raw(o, bad[s]);
       }
     }
   }
@@ -689,6 +698,7 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwtiles = (a.M + 16 * NS - 1) / (16 * NS), nsuper = (nwtiles + NW - 1) / NW;
+  NERF_STAMP2_DECL();
   RingW<L16::CHUNKS, L::F16_TOTAL, 4, NW> ws;
   ws.wsrc = reinterpret_cast<const char*>(a.wf);          // points at the 16x16x32 stream
   ws.lane16 = 16 * lane;
@@ -698,6 +708,7 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
   ring_load_bias(a.bias, L::BI_TOTAL);
   __syncthreads();
   NERF_STAMP_BEGIN();
+  NERF_STAMP2_LOOP();
   PeRegs<NS> cur;
   if (NERF_PE_HOIST) {
     const int64_t first = (int64_t)blockIdx.x * NW + wv;
@@ -713,8 +724,10 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
     }
     fwd_tiles16<NS>(a, ws, sp * NW + wv, (sp + gridDim.x) * NW + wv, nwtiles, ln, cur);
     NERF_STAMP_PASS();
+    NERF_STAMP2_PASS();
   }
   NERF_STAMP_END();
+  NERF_STAMP2_END();
   ws.drain();
 }
 
@@ -1136,6 +1149,7 @@ __device__ __forceinline__ void fwd_tiles_img(const ImgArgs& a, WS& ws, int64_t 
   bf16x8 xin[ST][3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) xin[0][ks] = row_frag(a.x + m * LI::CIN, ks, h, LI::CIN);
+  const int bad = nonfinite_flags<32>(nonfinite_bits(xin[0][0]) | nonfinite_bits(xin[0][1]) | nonfinite_bits(xin[0][2]), 0u);
   if (STORE) { store_frags<3>(a.acts, tile0, a.astride, LI::A_X, xin[0], r, h); ws.note_stores(3); }
   bf16x8 ha[ST][16], hb[ST][16];
   u32x4 mk[ST];
@@ -1175,7 +1189,7 @@ __device__ __forceinline__ void fwd_tiles_img(const ImgArgs& a, WS& ws, int64_t 
   if (h == 0 && tile0 < ntiles && mo < a.M) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      if (c < a.out_ch) a.out[mo * a.out_ch + c] = acc[c];                     // output_linear (models/NeRF.py:241)
+      if (c < a.out_ch) a.out[mo * a.out_ch + c] = bad ? __builtin_nanf("") : acc[c];      // output_linear (models/NeRF.py:241); NaN / Inf inputs: mlp_frag.h
   }
 }
 
@@ -1381,6 +1395,7 @@ __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
       xin[0][0] = row_frag(row, 0, h, LN::CPOS); xin[0][1] = row_frag(row, 1, h, LN::CPOS);
       din[0][0] = row_frag(row + LN::CPOS, 0, h, LN::CDIR);
     }
+    const int bad = nonfinite_flags<32>(nonfinite_bits(xin[0][0]) | nonfinite_bits(xin[0][1]), nonfinite_bits(din[0][0]));
 #define SINK(slot0) FragSink<STORE>{a.acts, tile0, a.astride, slot0, r, h}
 #define MASK_STORE(layer) do { if (STORE) *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0, a.astride, LN::A_MASK + (layer), r, h)) = mk[0]; } while (0)
     if (STORE) { store_frags<2>(a.acts, tile0, a.astride, LN::A_X, xin[0], r, h); store_frags<1>(a.acts, tile0, a.astride, LN::A_DX, din[0], r, h); }
@@ -1418,7 +1433,7 @@ __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
       for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws.frag(LN::F_RGB + ks, lane), hd[0][ks], acc, 0, 0, 0);
       if (h == 0 && valid) {
         float4 o; o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = alpha;
-        *reinterpret_cast<float4*>(a.out + m * 4) = o;
+        *reinterpret_cast<float4*>(a.out + m * 4) = poison_raw(o, bad);
       }
     }
 #undef SINK
@@ -1517,10 +1532,7 @@ static int cur_device() {
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
   return d;
 }
-struct DevOnce {
-  bool done[MAX_DEVICES] = {};
-  bool first() { const int d = cur_device(); if (done[d]) return false; done[d] = true; return true; }
-};
+// (DevOnce -- thread-safe per-device one-time set-up: common.h)
 static int cu_count() {
   static int n[MAX_DEVICES] = {};
   const int dev = cur_device();
@@ -1595,7 +1607,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
 }
 
 extern "C" int nerf_get_option(const char* key) {
-  if (!key) return -1;
+  if (!key) return NERF_OPTION_UNKNOWN;
   if (!strcmp(key, "mlp_variant")) return g_mlp_variant;
   if (!strcmp(key, "ring_workgroups")) return g_ring_wgs;
   if (!strcmp(key, "ring_split")) return g_ring_split;
@@ -1604,7 +1616,13 @@ extern "C" int nerf_get_option(const char* key) {
   if (!strcmp(key, "ngp_ray_major")) return g_ngp_ray_major;
   if (!strcmp(key, "dw22_variant")) return s16::g_dw_variant;
   if (!strcmp(key, "dw16_variant")) return g_dw16_variant;
-  return -1;
+  if (!strcmp(key, "tile_pad16")) return g_tile_pad16;
+  if (!strcmp(key, "dw_unit_bias")) return g_dw_bias;            // -1 = automatic (a legitimate value: unknown keys are INT_MIN)
+  if (!strcmp(key, "bwd_stage")) return g_bwd_stage;
+  if (!strcmp(key, "dw_job_mask")) return g_dw_job_mask;
+  if (!strcmp(key, "dw_private_tiles")) return g_dw_private;
+  if (!strcmp(key, "dw_ring_cap")) return g_dw_ring_cap;
+  return NERF_OPTION_UNKNOWN;
 }
 
 extern "C" int64_t nerf_mlp_param_count(const nerf_mlp_arch* arch) {
@@ -1711,9 +1729,7 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
     const int64_t nsuper = (M + 255) / 256;
     const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs()));
     static DevOnce once16;
-    if (once16.first()) {
-      ensure_lds(mlp_fwd_ring16_kernel<8, 2>, RING16_LDS_BYTES); ensure_lds(mlp_fwd_ring16_kernel<4, 4>, RING16_LDS_BYTES);
-    }
+    once16.run([&] { ensure_lds(mlp_fwd_ring16_kernel<8, 2>, RING16_LDS_BYTES); ensure_lds(mlp_fwd_ring16_kernel<4, 4>, RING16_LDS_BYTES); });
     FwdArgs a16 = a;
     a16.wf = reinterpret_cast<const bf16x8*>(base + L::F16_OFFSET);
     if (variant == 4) hipLaunchKernelGGL((mlp_fwd_ring16_kernel<8, 2>), g, dim3(512), RING16_LDS_BYTES, s, a16);
@@ -1725,7 +1741,7 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
       const int64_t nsuper = (ntiles + SPLIT_NW - 1) / SPLIT_NW;
       const int64_t wgs = 2 * (int64_t)ring_wgs();
       static DevOnce once2;
-      if (once2.first()) ensure_lds(mlp_fwd_ring_kernel<1, true, SPLIT_NW, SPLIT_CHUNK>, SPLIT_LDS_BYTES);
+      once2.run([&] { ensure_lds(mlp_fwd_ring_kernel<1, true, SPLIT_NW, SPLIT_CHUNK>, SPLIT_LDS_BYTES); });
       hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, true, SPLIT_NW, SPLIT_CHUNK>), dim3((unsigned)(nsuper < wgs ? nsuper : wgs)),
                          dim3(64 * SPLIT_NW), SPLIT_LDS_BYTES, s, a);
       return check_launch("mlp forward (ring, 2 workgroups per CU)");
@@ -1733,7 +1749,7 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
     const int64_t nsuper = (ntiles + 7) / 8;
     const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), b(512);
     static DevOnce once;
-    if (once.first()) { ensure_lds(mlp_fwd_ring_kernel<1, true>, RING_LDS_BYTES); ensure_lds(mlp_fwd_ring_kernel<1, false>, RING_LDS_BYTES); }
+    once.run([&] { ensure_lds(mlp_fwd_ring_kernel<1, true>, RING_LDS_BYTES); ensure_lds(mlp_fwd_ring_kernel<1, false>, RING_LDS_BYTES); });
     if (acts) hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, true>), g, b, RING_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((mlp_fwd_ring_kernel<1, false>), g, b, RING_LDS_BYTES, s, a);
     return check_launch("mlp forward (ring)");
@@ -1802,7 +1818,7 @@ extern "C" int nerf_mlp_forward_train(const nerf_mlp_arch* arch, const void* pac
     a.x = x; a.out = out; a.acts = acts; a.M = M;
     const int64_t nsuper = ((M + 31) / 32 + 7) / 8;
     static DevOnce once;
-    if (once.first()) { ensure_lds(mlp_img_fwd_ring_kernel<true>, RING_LDS_BYTES); ensure_lds(mlp_img_fwd_ring_kernel<false>, RING_LDS_BYTES); }
+    once.run([&] { ensure_lds(mlp_img_fwd_ring_kernel<true>, RING_LDS_BYTES); ensure_lds(mlp_img_fwd_ring_kernel<false>, RING_LDS_BYTES); });
     const dim3 g((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), b(512);
     if (acts) hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<true>, g, b, RING_LDS_BYTES, as_stream(stream), a);
     else hipLaunchKernelGGL(mlp_img_fwd_ring_kernel<false>, g, b, RING_LDS_BYTES, as_stream(stream), a);
@@ -1910,8 +1926,7 @@ static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, co
     rc = s16::launch_dw_kernel(d, nw, false, s);
   } else {
     static DevOnce lds_attr_set;
-    if (lds_attr_set.first())
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+    lds_attr_set.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES); });
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(nw), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
     rc = check_launch("mlp dW");
   }
@@ -2002,7 +2017,7 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
       a.d_out = d_raw; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M;
       const int64_t nsuper = (ntiles + 7) / 8;
       static DevOnce once_i;
-      if (once_i.first()) ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES);
+      once_i.run([&] { ensure_lds(mlp_img_bwd_ring_kernel, RING_LDS_BYTES); });
       hipLaunchKernelGGL(mlp_img_bwd_ring_kernel, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
                          RING_LDS_BYTES, s, a);
       rci = check_launch("mlp backward chain (image model)");
@@ -2044,13 +2059,13 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
       const int64_t nsuper = (ntiles + SPLIT_NW - 1) / SPLIT_NW;
       const int64_t wgs = 2 * (int64_t)ring_wgs();
       static DevOnce once2;
-      if (once2.first()) ensure_lds(mlp_bwd_ring_kernel<SPLIT_NW, SPLIT_CHUNK>, SPLIT_LDS_BYTES);
+      once2.run([&] { ensure_lds(mlp_bwd_ring_kernel<SPLIT_NW, SPLIT_CHUNK>, SPLIT_LDS_BYTES); });
       hipLaunchKernelGGL((mlp_bwd_ring_kernel<SPLIT_NW, SPLIT_CHUNK>), dim3((unsigned)(nsuper < wgs ? nsuper : wgs)),
                          dim3(64 * SPLIT_NW), SPLIT_LDS_BYTES, s, b);
     } else if (g_bwd_stage != 2) {
       const int64_t nsuper = (ntiles + 7) / 8;
       static DevOnce once;
-      if (once.first()) ensure_lds(mlp_bwd_ring_kernel<>, RING_LDS_BYTES);
+      once.run([&] { ensure_lds(mlp_bwd_ring_kernel<>, RING_LDS_BYTES); });
       hipLaunchKernelGGL(mlp_bwd_ring_kernel<>, dim3((unsigned)(nsuper < ring_wgs() ? nsuper : ring_wgs())), dim3(512),
                          RING_LDS_BYTES, s, b);
     }
@@ -2229,6 +2244,7 @@ extern "C" int nerf_mlp_debug_read(const nerf_mlp_arch* arch, const void* store,
   return check_launch("nerf_mlp_debug_read");
 }
 
+NERF_STAMP2_EXPORT(nerf_debug_stamps2_ring16)
 #ifdef NERF_CLOCK_STAMP
 extern "C" int nerf_debug_stamps(unsigned long long* host_out, int nwg) {
   if (nwg > 4096) nwg = 4096;

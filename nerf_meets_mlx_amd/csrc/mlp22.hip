@@ -210,7 +210,9 @@ __device__ __forceinline__ void layer22(WS& ws, int pbase, int bias_slot, const 
     }
 #endif
     float v0 = __builtin_fmaf(c[s][i], LO_INV, m[s][i]), v1 = __builtin_fmaf(c[s][i + 1], LO_INV, m[s][i + 1]);
-    if (RELU) { v0 = __builtin_fmaxf(v0, 0.0f); v1 = __builtin_fmaxf(v1, 0.0f); }
+    // v_maximum3_f32 (IEEE-754 maximum): a NaN pre-activation stays NaN like mx.maximum / nn.relu (models/NeRF.py:222,236);
+    // fmaxf (v_max_f32, maxNum) would return 0 for it
+    if (RELU) { v0 = __builtin_elementwise_maximum(v0, 0.0f); v1 = __builtin_elementwise_maximum(v1, 0.0f); }
     const HiLo q = split2(v0, v1);
     oh[s][nt >> 1][2 * (nt & 1) + (i >> 1)] = q.hi; ol[s][nt >> 1][2 * (nt & 1) + (i >> 1)] = q.lo;
 #if NERF_F22_AGPR
@@ -362,6 +364,7 @@ __global__ void __launch_bounds__(64 * NW22) mlp22_fwd_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwtiles = (a.M + 31) / 32, nsuper = (nwtiles + NW22 - 1) / NW22;
+  NERF_STAMP2_DECL();
   RingW<CHUNKS, F_FRAGS, 4, NW22, RING_CHUNK, RING_STAGES, true> ws;      // DMA runs of four (mlp_ring.h)
   ws.wsrc = reinterpret_cast<const char*>(a.wf);
   ws.lane16 = 16 * lane;
@@ -370,12 +373,15 @@ __global__ void __launch_bounds__(64 * NW22) mlp22_fwd_kernel(FwdArgs a) {
   ws.start(lane);
   ring_load_bias(a.bias, BIAS_FLOATS);
   __syncthreads();
+  NERF_STAMP2_LOOP();
   for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
     int ln = lane;
     asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
     ws.new_pass();
     tiles22<MODE>(a, ws, sp * NW22 + wv, nwtiles, ln);
+    NERF_STAMP2_PASS();
   }
+  NERF_STAMP2_END();
   ws.drain();                             // the ring always runs 3 chunks ahead
 }
 
@@ -401,15 +407,12 @@ int forward(const void* packed22, const float* x, const float* rays, const float
   const int64_t nsuper = ((M + 31) / 32 + NW22 - 1) / NW22;
   const dim3 g((unsigned)(nsuper < persistent_wgs ? nsuper : persistent_wgs)), b(64 * NW22);
   // dynamic LDS above 64 KiB is an opt-in per kernel AND per device
-  static bool done[64][2] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static DevOnce once[2];
   const int mode = x ? 0 : 1;
-  if (!done[dev][mode]) {
+  once[mode].run([&] {
     const void* k = mode == 0 ? reinterpret_cast<const void*>(mlp22_fwd_kernel<0>) : reinterpret_cast<const void*>(mlp22_fwd_kernel<1>);
     (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
-    done[dev][mode] = true;
-  }
+  });
   if (mode == 0) hipLaunchKernelGGL(mlp22_fwd_kernel<0>, g, b, RING_LDS_BYTES, s, a);
   else hipLaunchKernelGGL(mlp22_fwd_kernel<1>, g, b, RING_LDS_BYTES, s, a);
   return check_launch("mlp forward (split fp16)");
@@ -417,3 +420,4 @@ int forward(const void* packed22, const float* x, const float* rays, const float
 
 }  // namespace f22
 }  // namespace nerf
+NERF_STAMP2_EXPORT(nerf_debug_stamps2_mlp22)

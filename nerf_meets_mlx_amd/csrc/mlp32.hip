@@ -287,7 +287,7 @@ __device__ __forceinline__ void layer_fwd(const float4* __restrict__ wl, int fba
     unsigned bits = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float v = RELU ? fmaxf(acc[i], 0.0f) : acc[i];
+      const float v = RELU ? __builtin_elementwise_maximum(acc[i], 0.0f) : acc[i];     // NaN-propagating (v_maximum3_f32), like nn.relu
       const int row = 32 * nt + prow(i) + 4 * h;
       slab[row * 32 + col] = v;
       if (RELU) bits |= (v > 0.0f ? 1u : 0u) << i;

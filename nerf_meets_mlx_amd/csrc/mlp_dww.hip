@@ -239,14 +239,9 @@ __global__ void __launch_bounds__(64 * DWW_WAVES) mlp_dww_kernel(DwArgs a) {
 }
 
 int launch_dw_wide_kernel(const DwArgs& d, int workgroups, bool split_bf16, hipStream_t s) {
-  static bool done[2][64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static DevOnce once[2];
   const void* k = split_bf16 ? reinterpret_cast<const void*>(mlp_dww_kernel<true>) : reinterpret_cast<const void*>(mlp_dww_kernel<false>);
-  if (!done[split_bf16][dev]) {
-    done[split_bf16][dev] = true;
-    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DWW_LDS_BYTES);
-  }
+  once[split_bf16].run([&] { (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, DWW_LDS_BYTES); });
   if (split_bf16) hipLaunchKernelGGL(mlp_dww_kernel<true>, dim3(workgroups), dim3(64 * DWW_WAVES), DWW_LDS_BYTES, s, d);
   else hipLaunchKernelGGL(mlp_dww_kernel<false>, dim3(workgroups), dim3(64 * DWW_WAVES), DWW_LDS_BYTES, s, d);
   return check_launch(split_bf16 ? "mlp dW (split bf16, 256 x 256 jobs)" : "mlp dW (bf16, 256 x 256 jobs)");

@@ -152,6 +152,36 @@ __device__ __forceinline__ bf16x2 relu_pack(float a, float b) {
   q = __builtin_elementwise_max(q, zero);
   return __builtin_bit_cast(bf16x2, q);
 }
+// Non-finite INPUTS in the bf16 chains (round 6).  Their ReLU is a packed integer max on the bf16 bit patterns (relu_pack) and
+// returns 0 for a NaN pre-activation, where the reference's nn.relu = mx.maximum propagates it (models/NeRF.py:222,236: a NaN /
+// Inf position makes all four outputs NaN, a NaN / Inf view direction the three colours).  The float-ReLU kernels (precision 22
+// and 32) get that from v_maximum3_f32 at no cost; here a NaN-propagating ReLU would be a third VALU op per value pair, so the
+// chain instead flags a sample whose INPUT fragments hold a NaN / Inf (exponent field all ones) once, at the head of the pass,
+// and the output store writes NaN for it.  nonfinite_bits(f) != 0 <=> some element of the fragment is NaN / Inf.
+__device__ __forceinline__ unsigned nonfinite_bits(const bf16x8& f) {
+  const u32x4 w = __builtin_bit_cast(u32x4, f);
+  unsigned b = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b |= (w[i] & 0x7F807F80u) + 0x00800080u;       // 0x7F80 + 0x0080 = 0x8000: bit 15 of a half <=> exponent 0xFF
+  return b & 0x80008000u;
+}
+// bit 0: position inputs, bit 1: direction inputs; OR-ed over the lanes that share a sample (XOR_MASKS: lane-id bits that do not
+// select the sample -- 32 in the 32x32x16 chains, 16 | 32 in the 16x16x32 chains)
+template <int XOR_MASKS>
+__device__ __forceinline__ int nonfinite_flags(unsigned pos_bits, unsigned dir_bits) {
+  int f = (pos_bits ? 1 : 0) | (dir_bits ? 2 : 0);
+  if (XOR_MASKS & 16) f |= __shfl_xor(f, 16);
+  if (XOR_MASKS & 32) f |= __shfl_xor(f, 32);
+  return f;
+}
+// [rgb, alpha] of a flagged sample: position -> all NaN; direction only -> rgb NaN, alpha as computed (it does not depend on it)
+__device__ __forceinline__ float4 poison_raw(float4 o, int flags) {
+  const float qnan = __builtin_nanf("");
+  if (flags) { o.x = qnan; o.y = qnan; o.z = qnan; }
+  if (flags & 1) o.w = qnan;
+  return o;
+}
+
 // Packed 16-bit integer ops on bf16 bit patterns.  Inline asm on purpose: written as vector arithmetic, hipcc turns
 // them back into one float compare + select per element (and v_perm to re-pack), which is what they replace.
 // ReLU sign bits of a packed, already ReLU'd bf16 pair: 1 per non-zero half.

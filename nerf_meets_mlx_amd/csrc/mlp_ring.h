@@ -232,6 +232,52 @@ struct RingW {
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
+// Diagnostic build only (make stamp; tools/probe_launch_profile.py): where a launch of a persistent ring kernel spends its time --
+// per workgroup, the 100 MHz wall clock (s_memrealtime: one counter for the chip) at kernel entry, at the start of the pass loop
+// (ring primed, biases in LDS), after passes 1, 2, 4, 8, ... 128 and at the end, the shader clock (s_memtime) at four of those
+// points, the pass count and the hardware id (XCC, SE, CU).  One lane of wave 0 stores them; no output depends on them; in the
+// shipped build none of this exists.
+#ifdef NERF_CLOCK_STAMP
+static __device__ unsigned long long g_st2[4096][24];
+struct Stamp2 {
+  unsigned long long passes = 0;
+  __device__ __forceinline__ void put(int k, unsigned long long v) const {
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_st2[blockIdx.x][k] = v;
+  }
+  __device__ __forceinline__ void entry() const {
+    put(0, __builtin_amdgcn_s_memrealtime()); put(11, __builtin_amdgcn_s_memtime());
+    put(15, ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32)      // HW_REG_XCC_ID
+            | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));                               // HW_REG_HW_ID
+  }
+  __device__ __forceinline__ void loop_start() const { put(1, __builtin_amdgcn_s_memrealtime()); put(12, __builtin_amdgcn_s_memtime()); }
+  __device__ __forceinline__ void pass_done() {
+    ++passes;
+    if ((passes & (passes - 1)) == 0 && passes <= 128) {
+      put(2 + (63 - __builtin_clzll(passes)), __builtin_amdgcn_s_memrealtime());
+      if (passes == 1) put(16, __builtin_amdgcn_s_memtime());
+      if (passes == 8) put(17, __builtin_amdgcn_s_memtime());
+      if (passes == 32) put(18, __builtin_amdgcn_s_memtime());
+    }
+  }
+  __device__ __forceinline__ void end() const {
+    put(10, __builtin_amdgcn_s_memrealtime()); put(13, __builtin_amdgcn_s_memtime()); put(14, passes);
+  }
+};
+#define NERF_STAMP2_DECL() Stamp2 st2; st2.entry()
+#define NERF_STAMP2_LOOP() st2.loop_start()
+#define NERF_STAMP2_PASS() st2.pass_done()
+#define NERF_STAMP2_END() st2.end()
+#define NERF_STAMP2_EXPORT(name) extern "C" int name(unsigned long long* host_out, int nwg) { \
+  if (nwg > 4096) nwg = 4096; \
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nerf::g_st2), (size_t)nwg * 24 * 8) == hipSuccess ? 0 : -4; }
+#else
+#define NERF_STAMP2_DECL()
+#define NERF_STAMP2_LOOP()
+#define NERF_STAMP2_PASS()
+#define NERF_STAMP2_END()
+#define NERF_STAMP2_EXPORT(name)
+#endif
+
 template <class WS> struct is_ring { static constexpr bool value = false; };
 template <int N, int T, int G, int W, int C, int S, bool R> struct is_ring<RingW<N, T, G, W, C, S, R>> { static constexpr bool value = true; };
 

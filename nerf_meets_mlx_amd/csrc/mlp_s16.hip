@@ -686,16 +686,6 @@ __global__ void __launch_bounds__(64 * DW_WAVES) s16_dw_kernel(DwArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct DevOnce {
-  bool done[64] = {};
-  bool first() {
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
-    if (done[d]) return false;
-    done[d] = true;
-    return true;
-  }
-};
 
 int pack(const float* params, void* packed_s16, hipStream_t s) {
   char* base = static_cast<char*>(packed_s16);
@@ -717,10 +707,8 @@ int forward(const void* packed_s16, const float* bias_slots, const float* x, con
   // dynamic LDS above 64 KiB is an opt-in per kernel AND per device
   static DevOnce once[2];
   const int mode = x ? 0 : 1;
-  if (once[mode].first()) {
-    const void* k = mode == 0 ? reinterpret_cast<const void*>(s16_fwd_kernel<0>) : reinterpret_cast<const void*>(s16_fwd_kernel<1>);
-    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FwdRing::LDS_BYTES);
-  }
+  once[mode].run([&] { const void* k = mode == 0 ? reinterpret_cast<const void*>(s16_fwd_kernel<0>) : reinterpret_cast<const void*>(s16_fwd_kernel<1>);
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FwdRing::LDS_BYTES); });
   if (mode == 0) hipLaunchKernelGGL(s16_fwd_kernel<0>, g, b, FwdRing::LDS_BYTES, s, a);
   else hipLaunchKernelGGL(s16_fwd_kernel<1>, g, b, FwdRing::LDS_BYTES, s, a);
   return check_launch("mlp training forward (split bf16)");
@@ -733,8 +721,7 @@ int backward_chain(const void* packed_s16, const void* acts, const float* d_raw,
   b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz; b.astride = astride16; b.zstride = zstride16;
   const int64_t nsuper = ((M + 31) / 32 + NW - 1) / NW;
   static DevOnce once;
-  if (once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BwdRing::LDS_BYTES);
+  once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BwdRing::LDS_BYTES); });
   hipLaunchKernelGGL(s16_bwd_kernel, dim3((unsigned)(nsuper < persistent_wgs ? nsuper : persistent_wgs)), dim3(64 * NW),
                      BwdRing::LDS_BYTES, s, b);
   return check_launch("mlp backward chain (split bf16)");
@@ -744,9 +731,8 @@ int g_dw_variant = 1;          // nerf_set_option("dw22_variant"): 1 (default) 2
 
 int launch_dw_kernel(const DwArgs& d, int workgroups, bool split_bf16, hipStream_t s) {
   static DevOnce once[2];
-  if (once[split_bf16].first())
-    (void)hipFuncSetAttribute(split_bf16 ? reinterpret_cast<const void*>(s16_dw_kernel<true>) : reinterpret_cast<const void*>(s16_dw_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES);
+  once[split_bf16].run([&] { (void)hipFuncSetAttribute(split_bf16 ? reinterpret_cast<const void*>(s16_dw_kernel<true>) : reinterpret_cast<const void*>(s16_dw_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_BYTES); });
   if (split_bf16) hipLaunchKernelGGL(s16_dw_kernel<true>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
   else hipLaunchKernelGGL(s16_dw_kernel<false>, dim3(workgroups), dim3(64 * DW_WAVES), DW_LDS_BYTES, s, d);
   return check_launch(split_bf16 ? "mlp dW (split bf16)" : "mlp dW (bf16)");

@@ -18,10 +18,9 @@ __device__ __forceinline__ HL split2(float a, float b) {
   o.l = pack2(a - h0, b - h1);                                             // exact differences
   return o;
 }
-__device__ __forceinline__ float relu_bits(float v) {                      // one v_max_i32 on the bit pattern
-  const int b = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, b > 0 ? b : 0);
-}
+// one v_maximum3_f32 (IEEE-754 maximum: a NaN pre-activation stays NaN like mx.maximum / nn.relu, models/NeRF.py:222,236; the
+// integer max on the bit pattern it replaces turned a negative-signed NaN into 0)
+__device__ __forceinline__ float relu_bits(float v) { return __builtin_elementwise_maximum(v, 0.0f); }
 template <int COUNT>
 __device__ __forceinline__ void split_slots(const float (&v)[COUNT], bf16x8* hi, bf16x8* lo) {
 #pragma unroll

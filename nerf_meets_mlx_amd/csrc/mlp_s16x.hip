@@ -31,16 +31,6 @@ static_assert(SM_A_LO == LN::A_MASK && SM_A_MASK == 2 * LN::A_MASK && SM_A_SLOTS
 static_assert(SM_Z_LO == LN::Z_SLOTS && SM_Z_SLOTS == 2 * LN::Z_SLOTS, "2x64 dZ slots");
 static_assert(SM_F_FRAGS == 2 * LN::F_PADDED && SM_B_FRAGS == 2 * LN::B_PADDED, "2x64 pair streams");
 
-struct DevOnce {
-  bool done[64] = {};
-  bool first() {
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
-    if (done[d]) return false;
-    done[d] = true;
-    return true;
-  }
-};
 
 // ==========================================================================================
 // image model
@@ -467,10 +457,9 @@ int img_forward(const void* packed, const float* bias_slots, const float* x, int
   const int64_t nsuper = ((M + 31) / 32 + NW - 1) / NW;
   const dim3 g((unsigned)(nsuper < persistent_wgs ? nsuper : persistent_wgs)), b(64 * NW);
   static DevOnce once;
-  if (once.first()) {                      // dynamic LDS above 64 KiB is an opt-in per kernel AND per device
+  once.run([&] { // dynamic LDS above 64 KiB is an opt-in per kernel AND per device
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_img_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ImgFwdRing::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_img_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ImgFwdRing::LDS_BYTES);
-  }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_img_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ImgFwdRing::LDS_BYTES); });
   if (acts) hipLaunchKernelGGL(s16_img_fwd_kernel<true>, g, b, ImgFwdRing::LDS_BYTES, s, a);
   else hipLaunchKernelGGL(s16_img_fwd_kernel<false>, g, b, ImgFwdRing::LDS_BYTES, s, a);
   return check_launch("mlp forward (image model, split bf16)");
@@ -483,8 +472,7 @@ int img_backward_chain(const void* packed, const void* acts, const float* d_out,
   a.d_out = d_out; a.acts = const_cast<void*>(acts); a.dz = dz; a.M = M;
   const int64_t nsuper = ((M + 31) / 32 + NW - 1) / NW;
   static DevOnce once;
-  if (once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_img_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ImgBwdRing::LDS_BYTES);
+  once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s16_img_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ImgBwdRing::LDS_BYTES); });
   hipLaunchKernelGGL(s16_img_bwd_kernel, dim3((unsigned)(nsuper < persistent_wgs ? nsuper : persistent_wgs)), dim3(64 * NW),
                      ImgBwdRing::LDS_BYTES, s, a);
   return check_launch("mlp backward chain (image model, split bf16)");
@@ -511,7 +499,7 @@ static void small_fill(SmallArgs& a, const void* packed, const float* bias_slots
 
 template <class K>
 static void want_lds(K kernel, DevOnce& once) {
-  if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
+  once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES); });
 }
 
 int small_forward(const void* packed, const float* bias_slots, const float* x, int64_t M, float* out, void* acts,

@@ -356,6 +356,13 @@ class NGPTrainer(Trainer):
                                "save from rank 0")
         return super().state_dict()
 
+    def load_state_dict(self, sd, allow_legacy_rng: bool = False):
+        """Joins the comm stream first (the table all-gathers of a sharded step may still be writing the buffers this loads into),
+        and a loaded state is complete on every rank: the moments count as synced until the next sharded step."""
+        self._join_comm()
+        super().load_state_dict(sd, allow_legacy_rng=allow_legacy_rng)
+        self._moments_synced = True
+
     def _checkpoint_buffers(self):
         """Trainer.save / load / state_dict / load_state_dict work on these: the 2 x 64 MLP and the hash tables, with
         their two Adam (m, v) pairs and step counts (bias correction is on here, so the counts matter)."""

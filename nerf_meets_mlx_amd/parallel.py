@@ -45,6 +45,39 @@ def barrier():
             dist.barrier()
 
 
+def comm_info(device=None, allreduce_bytes_per_step: int = 0, collectives_per_step: int = 0) -> dict:
+    """What the communicator of this job IS, as seen from inside it (bench.py prints it in the `--gpus N` line so that a
+    scaling record explains itself): backend name, the world size the process group reports, the number of ranks that
+    actually answered a sum all-reduce of ones (`world_size_seen`: a collective, every rank calls this), the RCCL version
+    torch was built against (`torch.cuda.nccl.version()`; None without it), each rank's device, and the bytes the data path
+    all-reduces per step.  One process: no communicator, world_size_seen 1."""
+    info = {"backend": None, "world_size": 1, "world_size_seen": 1, "rccl_version": None, "devices": None,
+            "allreduce_bytes_per_step": int(allreduce_bytes_per_step), "collectives_per_step": int(collectives_per_step)}
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:                                      # CPU-only build / no RCCL in this torch
+        pass
+    if not (dist.is_available() and dist.is_initialized()):
+        return info
+    ws = dist.get_world_size()
+    backend = dist.get_backend()
+    on_gpu = backend == "nccl" or (device is not None and torch.device(device).type == "cuda")
+    dev = torch.device(device if device is not None else ("cuda" if on_gpu else "cpu"))
+    one = torch.ones(1, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = {"rank": dist.get_rank(), "device": str(dev)}
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        mine.update(index=dev.index if dev.index is not None else torch.cuda.current_device(), name=pr.name,
+                    arch=getattr(pr, "gcnArchName", None))
+    every = [None] * ws
+    dist.all_gather_object(every, mine)
+    info.update(backend="rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, world_size=ws,
+                world_size_seen=int(round(float(one[0]))), devices=every)
+    return info
+
+
 def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) slice of n units for `rank`; slices are disjoint and cover [0, n)."""
     return n * rank // world_size, n * (rank + 1) // world_size

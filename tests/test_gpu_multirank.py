@@ -153,6 +153,17 @@ def _ngp_worker(rank, world, port, q, tmp):
         same = same and all(torch.equal(mvs[0], t) for t in mvs) and float(mv.abs().max()) > 0
         finals[(det, sync, prec)] = (tr.field.enc.tables.clone(), mv)
         res.append((det, same and shadow_ok, moved, cleared, float(out["loss_coarse"])))
+        if sync == "shard":
+            # round 6 (advisor): a load right after a sharded step -- table all-gathers still queued on the comm stream, moments
+            # stale -- joins that stream first and leaves a complete state: state_dict() works at once, tables are the file's
+            parallel.barrier()                                   # rank 0's file is written
+            tr.train_step()
+            assert not tr._moments_synced
+            tr.load(os.path.join(tmp, f"ngp_{int(det)}_{sync}_{prec}.npz"))
+            sd2 = tr.state_dict()
+            same = same and torch.equal(sd2["params"]["tables"], sd["params"]["tables"]) and tr.it == 3
+            same = same and torch.equal(sd2["adam"]["state"]["tables"][0], sd["adam"]["state"]["tables"][0])
+            res[-1] = (det, same and shadow_ok, moved, cleared, float(out["loss_coarse"]))
     # exact integer sums: the sharded schedule lands on the all-reduce schedule's tables and moments bit for bit
     eq = torch.equal(finals[(True, "shard", 22)][0], finals[(True, "allreduce", 22)][0]) and torch.equal(finals[(True, "shard", 22)][1], finals[(True, "allreduce", 22)][1])
     res.append((True, eq, True, True, 0.0))

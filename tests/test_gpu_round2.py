@@ -430,6 +430,26 @@ def test_entrypoint_checkpoint_flags(tmp_path):
     assert r3["resumed_from"] is None and r3["losses"][0][0] == 1
     r4 = test_nerf.main(None, max_iter=9, argv=base + ["--no_reload", "--ft_path", r1["checkpoints"][0]], **kw)
     assert r4["resumed_from"] == r1["checkpoints"][0] and r4["losses"][0][0] == 5
+    # round 6: the run log (engine/runlog.py; __test_nerf.py:298-299 keeps loss.item() per iteration): the four runs of
+    # {basedir}/run appended to ONE log.jsonl -- a `run` record each, a `train` record per logged iteration whose losses are
+    # the returned ones, a positive whole-job rays/s, the scheduled learning rate
+    from nerf_meets_mlx_amd.engine import runlog
+    recs = runlog.read(os.path.join(str(tmp_path), "run", "log.jsonl"))
+    assert r2["log"] == os.path.join(str(tmp_path), "run", "log.jsonl")
+    runs = [r for r in recs if r["kind"] == "run"]
+    assert len(runs) == 4 and [r["start_it"] for r in runs] == [0, 4, 0, 4] and runs[1]["resumed_from"].endswith("000004.npz")
+    assert all(r["precision"] == 22 and r["n_rand"] == 1024 and r["world_size"] == 1 for r in runs)
+    train = [r for r in recs if r["kind"] == "train"]
+    assert [r["it"] for r in train] == list(range(1, 7)) + list(range(5, 11)) + list(range(1, 6)) + list(range(5, 10))
+    by_it = {r["it"]: r for r in train[6:12]}
+    for it, lc, lf in r2["losses"]:
+        assert by_it[it]["loss_coarse"] == lc and by_it[it]["loss_fine"] == lf
+        assert abs(by_it[it]["lr"] - 5e-4 * 0.1 ** ((it - 1) / 500000)) < 1e-12 and by_it[it]["rays_per_s"] > 0
+        assert abs(by_it[it]["psnr_fine"] + 10 * np.log10(lf)) < 1e-9
+    full_log = runlog.read(full["log"])
+    assert [r["it"] for r in full_log if r["kind"] == "train"] == list(range(1, 11))
+    off = test_nerf.main(None, max_iter=2, argv=["--basedir", str(tmp_path), "--expname", "nolog", "--i_weights", "0"], write_log=False, **kw)
+    assert off["log"] is None and not os.path.exists(os.path.join(str(tmp_path), "nolog", "log.jsonl"))
 
 
 # ------------------------------------------------------------------------------ guards
@@ -460,7 +480,7 @@ def test_stale_activation_and_stale_weight_guards():
     L = NV.lib()
     assert L.nerf_set_option(b"mlp_precision", 32) == -3 and b"nerf_mlp_arch.precision" in L.nerf_last_error()   # ABI 3: not an option
     assert L.nerf_set_option(b"ring_split", 3) == -3
-    assert L.nerf_get_option(b"mlp_precision") == -1 and L.nerf_get_option(b"ring_split") == 1
+    assert L.nerf_get_option(b"mlp_precision") == -2 ** 31 and L.nerf_get_option(b"ring_split") == 1
     zz = torch.rand(4, 8, device=DEV)
     assert L.nerf_add_noise_z(NV.ptr(zz), NV.ptr(zz), 4, 8, 1.0, NV.ptr(zz), None) == -2        # in place is refused
     # precision belongs to the model: an arch with an unknown precision, or fp32 for a model without fp32 kernels, is refused
@@ -535,7 +555,7 @@ def _write_blender_scene(root, hw=40, n_train=6, n_val=2, n_test=2):
         with open(os.path.join(data, f"transforms_{split}.json"), "w") as fp:
             json.dump({"camera_angle_x": synthetic.CAMERA_ANGLE_X, "frames": frames}, fp)
     with open(os.path.join(root, "configs", "lego.txt"), "w") as fp:
-        fp.write("expname = blender_paper_lego\nbasedir = ./logs\ndatadir = ./data/lego\ndataset_type = blender\n\n"
+        fp.write(f"expname = blender_paper_lego\nbasedir = {root}/logs\ndatadir = ./data/lego\ndataset_type = blender\n\n"
                  "no_batching = True\n\nuse_viewdirs = True\nwhite_bkgd = True\nlrate_decay = 500\n\n"
                  "N_samples = 64\nN_importance = 128\nN_rand = 1024\n\nprecrop_iters = 500\nprecrop_frac = 0.5\n\nhalf_res = True\n")
 
@@ -552,7 +572,13 @@ def test_entrypoint_on_a_blender_dataset_on_disk(tmp_path):
     os.makedirs(root)
     _write_blender_scene(root)
     res = test_nerf.main(root, max_iter=60, log_every=10, render_every=60, n_render_poses=1, seed=4)
+    assert res["log"] == os.path.join(root, "logs", "blender_paper_lego", "log.jsonl")      # basedir / expname of lego.txt
     tr = res["trainer"]
+    from nerf_meets_mlx_amd.engine import runlog
+    recs = runlog.read(res["log"])                          # {basedir}/{expname from lego.txt}/log.jsonl: 6 train records + the i_render frame's PSNR
+    ev = [r for r in recs if r["kind"] == "eval"]
+    assert [r["it"] for r in recs if r["kind"] == "train"] == [10, 20, 30, 40, 50, 60] and len(ev) == 1 and ev[0]["it"] == 60
+    assert 5.0 < ev[0]["psnr"] < 60.0 and ev[0]["view"] == 3 and recs[0]["dataset"] == root
     assert tr.H == 40 and tr.W == 40 and tr.N_rand == 1024 and tr.n == 64 and tr.N == 128          # native resolution (Q3)
     assert abs(tr.K[0, 0] - 0.5 * 40 / np.tan(0.5 * 0.6911112070083618)) < 1e-9 and tr.images.shape == (6, 40, 40, 3)
     png = np.asarray(Image.open(os.path.join(root, "data", "lego", "train", "r_0.png"))).astype(np.float32) / 255.0

@@ -160,28 +160,35 @@ def test_ngp_deterministic_scatter_surfaces_nonfinite_and_out_of_range_gradients
 
 
 def test_ngp_deterministic_scatter_single_negative_saturated_addend_is_nan():
-    """The poisoned window is symmetric (advisor, round 4): ONE addend below -256 on an otherwise untouched entry saturates to
-    -2^60 units exactly and must come back as NaN, like +2^60 does -- not as a finite -256 gradient."""
+    """The poisoned window is symmetric (advisor, round 4): ONE addend below -256 on an otherwise untouched entry must come back as
+    NaN, like one above +256 does -- not as a finite -256 gradient.  Round 6 (advisor, round 5): saturated addends sit at
+    +-1.5 x 2^60 units, half a window OUTSIDE (-2^60, 2^60), so that ordinary addends of either sign on the SAME entry (the
+    common case on coarse levels) cannot pull the sum back inside: a second sample in the same cell adds +-100 per corner."""
     import ctypes as C
     from nerf_meets_mlx_amd import _native as N
     L, log2T, F = 2, 8, 2
     res = (C.c_int * L)(4, 8)
-    x = torch.tensor([[0.3, 0.6, 0.2]], device=DEV)
-    for sign in (-1.0, 1.0):
-        d_out = torch.zeros(1, L * F, device=DEV)
+    for sign, other in ((-1.0, 0.0), (1.0, 0.0), (-1.0, 100.0), (-1.0, -100.0), (1.0, 100.0), (1.0, -100.0)):
+        # sample 0 carries the saturating gradient; samples 1..3 sit at the same point (same eight corners, same weights) with an
+        # ordinary gradient of +-100 each: 3 x 100 x w <= 300 x w with every corner weight w <= 0.4 here -> |sum| < 128
+        x = torch.tensor([[0.3, 0.6, 0.2]] * 4, device=DEV)
+        d_out = torch.zeros(4, L * F, device=DEV)
         d_out[0, 0] = sign * 1e9                              # feature 0 of level 0: every corner weight x 1e9 is far beyond 256
+        d_out[1:, 0] = other
         acc = torch.zeros(L, 1 << log2T, F, dtype=torch.int64, device=DEV)
-        N.check(N.lib().nerf_hashgrid_backward_ex(N.ptr(x), 1, N.ptr(d_out), L, log2T, F, res, 0, L, 1, N.ptr(acc), N.stream()))
+        N.check(N.lib().nerf_hashgrid_backward_ex(N.ptr(x), 4, N.ptr(d_out), L, log2T, F, res, 0, L, 1, N.ptr(acc), N.stream()))
         touched = acc[0, :, 0] != 0
         assert 1 <= int(touched.sum()) <= 8
-        assert bool((acc[0, touched, 0] * int(sign) >= (1 << 60)).all())       # saturated (a corner alone on its entry: exactly +-2^60)
+        assert bool((acc[0, touched, 0] * int(sign) >= (1 << 60)).all()), (sign, other)       # outside the window WITH the ordinary addends
+        if other == 0.0:
+            assert bool((acc[0, touched, 0] * int(sign) == (1 << 60) + (1 << 59)).all())     # a corner alone on its entry: exactly +-1.5 x 2^60
         params = torch.zeros(acc.numel(), device=DEV)
         m, v = torch.zeros_like(params), torch.zeros_like(params)
         N.check(N.lib().nerf_adam_step_ex(N.ptr(params), N.ptr(acc), N.ptr(m), N.ptr(v), params.numel(), 1e-3, 0.9, 0.99, 1e-8, 1, 1, 1.0,
                                           1, 1, N.stream()))
         torch.cuda.synchronize()
         p = params.view(L, 1 << log2T, F)
-        assert bool(torch.isnan(p[0, touched, 0]).all()), sign
+        assert bool(torch.isnan(p[0, touched, 0]).all()), (sign, other)
         assert bool(torch.isfinite(p[0, ~touched, 0]).all()) and bool(torch.isfinite(p[1]).all())
         assert int(acc.abs().max()) == 0
 

@@ -1,0 +1,355 @@
+"""Round-6 GPU tests: the three parity holes of the round-5 review.
+
+  * non-finite INPUTS propagate like the reference's `nn.relu = mx.maximum` does (models/NeRF.py:222,236) in every fused MLP
+    chain, every precision, every entry point -- checked against the oracle's own NaN pattern on the same poisoned inputs;
+  * BASELINE configs[1]: the coarse-only trainer (N_importance = 0, bf16) against `OracleTrainer(..., n_importance=0,
+    emulate_bf16)` (rendering/render.py:112-162 + __test_nerf.py:47-90), plus one 400 x 400 step + frame;
+  * a15: the exact count of importance-sampler bin indices that differ from the reference's own output, per fixture.
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+
+
+POISON = {"+nan": 0x7FC00000, "-nan": 0xFFC00000, "+inf": 0x7F800000, "-inf": 0xFF800000}      # x86 makes -nan (0/0), numpy's constant is +nan
+
+
+def _put(t, idx, u):
+    t.view(torch.int32)[idx] = u if u < 2 ** 31 else u - 2 ** 32
+
+
+def _view_model(precision, seed=0):
+    from nerf_meets_mlx_amd.models.NeRF import NeRF
+    arch = O.NerfArch()
+    m = NeRF(channel_input=63, channel_input_views=27, is_use_view_directions=True, device=DEV, seed=seed, precision=precision)
+    return m, arch, O.unflatten_params(arch, m.params.cpu())
+
+
+def _rays(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(B, 3, generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    return O.pack_rays(o, d, 2.0, 6.0)
+
+
+# ------------------------------------------------------------------------------------------------ 1a: NaN / Inf inputs
+@pytest.mark.parametrize("precision", [22, 32, 16])
+def test_non_finite_inputs_propagate_like_the_reference(precision):
+    """One poisoned ray in a batch (NaN or Inf of either sign in its origin, its direction, its view direction, or one depth):
+    the NaN pattern of `query()` -- inference and training forward -- is the ORACLE's on the same inputs (position -> all four
+    outputs of the sample NaN; view direction -> rgb NaN, alpha finite and bit-identical to the clean run), and every other
+    ray is bit-identical to the clean run.  Same for `forward(x)` on embedded rows.  (Rounds 1-5 returned finite, meaningless
+    values: `max(NaN, 0)` of the hardware's v_max_f32 / integer max is 0.)"""
+    m, arch, p = _view_model(precision)
+    B, n, bad = 70, 64, 17
+    rays = _rays(B, 3)
+    z = torch.linspace(2.0, 6.0, n).expand(B, n).contiguous()
+    rd, zd = rays.to(DEV), z.to(DEV)
+
+    def oracle_nan(r, zz):
+        pts = r[:, None, 0:3] + zz[..., None] * r[:, None, 3:6]
+        return torch.isnan(O.run_model(arch, p, pts, r[:, 8:11]))
+
+    for train in (False, True):
+        clean = m.query(rd, zd, train=train).clone()
+        assert torch.isfinite(clean).all()
+        for name, u in POISON.items():
+            for col in (1, 4, 9):                                       # origin y, direction x (enters pts), view direction y
+                r2 = rays.clone()
+                _put(r2, (bad, col), u)
+                raw = m.query(r2.to(DEV), zd, train=train).cpu()
+                want = oracle_nan(r2[bad:bad + 1], z[bad:bad + 1])[0]
+                assert torch.equal(torch.isnan(raw[bad]), want), (precision, train, name, col)
+                assert bool(want[:, :3].all()) and bool(want[:, 3].all()) == (col != 9)
+                keep = torch.arange(B) != bad
+                assert torch.equal(raw[keep], clean.cpu()[keep]), (precision, train, name, col)
+                if col == 9:                                            # alpha does not depend on the view direction
+                    assert torch.equal(raw[bad, :, 3], clean.cpu()[bad, :, 3])
+            z2 = z.clone()
+            _put(z2, (bad, 5), u)
+            raw = m.query(rd, z2.to(DEV), train=train).cpu()
+            nanmap = torch.isnan(raw)
+            assert bool(nanmap[bad, 5].all()) and int(nanmap.sum()) == 4, (precision, train, name)
+            assert torch.equal(raw[~nanmap], clean.cpu()[~nanmap])
+    # embedded rows: NeRF.forward(x)
+    pts = rays[:, None, 0:3] + z[..., None] * rays[:, None, 3:6]
+    x = O.embed(pts, rays[:, 8:11]).reshape(-1, 90).contiguous()
+    clean = m.forward(x.to(DEV)).cpu()
+    row = 1000
+    for name, u in POISON.items():
+        for col in (0, 31, 62, 63, 89):
+            x2 = x.clone()
+            _put(x2, (row, col), u)
+            out = m.forward(x2.to(DEV)).cpu()
+            want = torch.isnan(O.nerf_forward(arch, p, x2[row:row + 1]))[0]
+            assert torch.equal(torch.isnan(out[row]), want), (precision, name, col, out[row])
+            assert bool(want[:3].all()) and bool(want[3]) == (col < 63)
+            keep = torch.arange(x.shape[0]) != row
+            assert torch.equal(out[keep], clean[keep])
+
+
+@pytest.mark.parametrize("precision", [22, 32, 16])
+def test_non_finite_inputs_image_and_small_models(precision):
+    """The image-fitting model (models/NeRF.py:196-197,241) and the 2 x 64 model of configs[4]: a NaN / Inf input feature makes
+    the outputs NaN exactly where the oracle's are; the other rows are bit-identical to the clean run."""
+    from tests.test_gpu_round5 import _image_pair, _small_pair
+    g = torch.Generator().manual_seed(5)
+    m, arch, flat = _image_pair(precision)
+    p = O.unflatten_params(arch, flat)
+    x = torch.randn(300, 40, generator=g)
+    clean = m.forward(x.to(DEV)).cpu()
+    for name, u in POISON.items():
+        for col in (0, 39):
+            for train in (False, True):
+                x2 = x.clone()
+                _put(x2, (100, col), u)
+                out = m.forward(x2.to(DEV), train=train).cpu()
+                want = torch.isnan(O.nerf_forward(arch, p, x2[100:101]))[0]
+                assert bool(want.all()) and torch.equal(torch.isnan(out[100]), want), (name, col, train, out[100])
+                keep = torch.arange(300) != 100
+                assert torch.equal(out[keep], clean[keep])
+    if precision == 32:
+        return                                                           # the 2 x 64 model has no fp32-MFMA kernels (refused)
+    m, arch, flat = _small_pair(precision)
+    p = O.unflatten_params(arch, flat)
+    x = torch.randn(300, 48, generator=g)
+    clean = m.forward(x.to(DEV)).cpu()
+    for name, u in POISON.items():
+        for col in (3, 31, 32, 47):
+            for train in (False, True):
+                x2 = x.clone()
+                _put(x2, (100, col), u)
+                out = m.forward(x2.to(DEV), train=train).cpu()
+                want = torch.isnan(O.nerf_forward(arch, p, x2[100:101]))[0]
+                assert torch.equal(torch.isnan(out[100]), want), (name, col, train, out[100])
+                assert bool(want[:3].all()) and bool(want[3]) == (col < 32)
+                keep = torch.arange(300) != 100
+                assert torch.equal(out[keep], clean[keep])
+
+
+@pytest.mark.parametrize("precision", [22, 32, 16])
+def test_a_non_finite_ray_makes_the_training_step_non_finite(precision):
+    """The reference's loss is a mean over the batch (`__test_nerf.py:47-90`): one NaN ray -> NaN loss -> NaN gradients -> NaN
+    parameters after Adam.  Here: the loss is NaN, the poisoned ray's d_raw is NaN, the parameter gradient holds NaN (precision 22 /
+    32: the stored activations of that sample are NaN, so every weight that multiplies them is; bf16: every layer has NaN rows), and after one
+    optimiser step + re-query every output is NaN -- a poisoned batch cannot train on silently."""
+    from nerf_meets_mlx_amd.models.NeRF import Adam
+    from nerf_meets_mlx_amd.rendering import render
+    m, arch, p = _view_model(precision, seed=4)
+    B, n = 40, 64
+    rays = _rays(B, 9)
+    _put(rays, (11, 0), POISON["-nan"])
+    rd = rays.to(DEV)
+    z = torch.linspace(2.0, 6.0, n, device=DEV).expand(B, n).contiguous()
+    target = torch.rand(B, 3, device=DEV)
+    raw = m.query(rd, z, train=True)
+    loss, d_raw, _ = render.composite_mse_backward(raw, z, rd, target, True)
+    assert torch.isnan(loss).all() and torch.isnan(d_raw[11, :, :3]).all()      # (d sigma is [x > 0]-gated: 0 where the comparison is false)
+    keep = torch.arange(B, device=DEV) != 11
+    assert torch.isfinite(d_raw[keep]).all()
+    grads = m.backward(d_raw)
+    off, layers_with_nan = 0, []
+    for name, o_, i_ in arch.layer_shapes():
+        w = grads[off:off + o_ * i_]
+        off += o_ * i_ + o_
+        if bool(torch.isnan(w).any()):
+            layers_with_nan.append(name)
+        # layers whose whole input is the (NaN) hidden state of the poisoned sample: every entry is NaN whatever the ReLU' of a NaN
+        # is taken to be (0 x NaN = NaN); pos0 / pos5 / dir0 also read encodings of which only the x channels are NaN here
+        if precision != 16 and name in ("pos1", "pos2", "pos3", "pos4", "pos6", "pos7", "feature", "alpha", "rgb"):
+            assert torch.isnan(w).all(), name
+    print(f"precision {precision}: layers with NaN weight gradients after one poisoned ray: {layers_with_nan}")
+    if precision != 16:
+        assert len(layers_with_nan) == len(arch.layer_shapes())
+    else:
+        # bf16 (declared reduced precision): the stored activations of the poisoned sample are finite (its ReLUs return 0 for NaN;
+        # only the OUTPUT is forced to NaN, csrc/mlp_frag.h), so NaN enters the weight gradients through d_raw alone: d sigma is
+        # [x > 0]-gated to 0, the colour gradient is NaN -> the colour branch and every trunk layer behind `feature`
+        assert {"rgb", "dir0", "feature", "pos7", "pos0"} <= set(layers_with_nan), layers_with_nan
+    Adam(5e-4).update(m, grads)
+    assert torch.isnan(m.query(rd, z)).all()
+
+
+# ------------------------------------------------------------------------------------------------ 1b: BASELINE configs[1]
+def _lego_K(H, W):
+    f = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+    return np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]], dtype=np.float64)
+
+
+@pytest.mark.parametrize("precision,emulate", [(16, True), (22, False)])
+def test_coarse_only_trainer_matches_oracle_trainer(precision, emulate):
+    """BASELINE configs[1] (coarse-only NeRF, 64 samples per ray, bf16): `Trainer(N_importance=0)` takes its own branch -- no
+    fine network, no importance pass, ONE Adam step per iteration -- whose reference counterpart is `render_rays` + `mlx_mse_coarse`
+    (rendering/render.py:112-162, entrypoints/__test_nerf.py:47-90).  Same rays / targets through the HIP trainer and
+    `OracleTrainer(n_importance=0)`: bf16 against the bf16-EMULATING oracle at the tolerances of
+    test_trainer_matches_oracle_trainer (3 % for two iterations, 12 % for the next two), the default precision against the
+    float32 oracle (1e-3 / 2 %); then parameters, learning-rate schedule, the single Adam state, checkpoint continuation and
+    the coarse-only renderer against the oracle's render_rays on the TRAINED weights."""
+    from nerf_meets_mlx_amd.engine.trainer import Trainer
+    H = W = 8
+    g = torch.Generator().manual_seed(2)
+    imgs = torch.rand(2, H, W, 3, generator=g)
+    poses = torch.stack([O.pose_spherical(10.0, -30.0, 4.0), O.pose_spherical(100.0, -40.0, 4.0)])
+    tr = Trainer(imgs, poses, _lego_K(H, W), N_rand=48, n_depth_samples=64, N_importance=0, seed=11, device=DEV, precision=precision)
+    assert tr.fine is None and tr.coarse.precision == precision
+    ot = O.OracleTrainer(O.NerfArch(), 64, 0, seed=11, emulate_bf16=emulate)
+    assert ot.pf is None and torch.equal(tr.coarse.params.cpu(), ot.pc.detach())
+    for it in range(4):
+        rays, target = tr.sample_batch()
+        got = tr.train_step(rays, target)
+        want = ot.step(rays[:, 0:3].cpu(), rays[:, 3:6].cpu(), target.cpu(), None)
+        assert set(got) == {"loss_coarse"} and set(want) == {"loss_coarse"}
+        tol = (3e-2 if it < 2 else 1.2e-1) if precision == 16 else (1e-3 if it < 2 else 2e-2)
+        assert abs(float(got["loss_coarse"]) - want["loss_coarse"]) < tol * abs(want["loss_coarse"]) + 1e-5, (it, float(got["loss_coarse"]), want)
+        assert abs(tr.opt.learning_rate * 0.1 ** (1 / 500000) - ot.lr) < 1e-9
+    assert list(tr.opt.state) == ["shared"] and tr.opt.step_count["shared"] == 4          # ONE Adam step per iteration
+    dp = (tr.coarse.params.cpu() - ot.pc.detach()).abs()
+    assert float(dp.mean()) < 6e-4, float(dp.mean())
+    # the coarse-only renderer on the trained weights (render_rays, :112-162): rgb / disp / acc against the oracle
+    rays = _rays(33, 21).to(DEV)
+    p = O.unflatten_params(O.NerfArch(), tr.coarse.params.detach().cpu())
+    want = O.render_rays(O.NerfArch(), p, rays.cpu(), 64, white_bkgd=True, emulate_bf16=emulate, retraw=True)
+    rgb = tr.render_rays(rays).cpu()
+    tol = 2e-2 if precision == 16 else 1e-4
+    assert float((rgb - want["rgb_map"]).abs().max()) < tol, float((rgb - want["rgb_map"]).abs().max())
+    # checkpoint: the coarse-only state continues bit-identically
+    sd = tr.state_dict()
+    assert set(sd["params"]) == {"coarse"}
+    tr2 = Trainer(imgs, poses, _lego_K(H, W), N_rand=48, n_depth_samples=64, N_importance=0, seed=3, device=DEV, precision=precision)
+    tr2.load_state_dict(sd)
+    a, b = tr.train_step(), tr2.train_step()
+    assert abs(float(a["loss_coarse"]) - float(b["loss_coarse"])) < 1e-6 * abs(float(a["loss_coarse"]))      # (the loss scalar is a float-atomic sum)
+    assert torch.equal(tr.coarse.params, tr2.coarse.params)
+
+
+def test_coarse_only_configs1_at_400x400():
+    """configs[1] at its own size (Lego 400 x 400, 64 samples per ray, bf16), as a property run: training steps at N_rand 4096 lower
+    the loss on the synthetic scene, a full 400 x 400 frame through the coarse-only renderer is finite, and a strip of that
+    frame agrees with the bf16-emulating oracle's render_rays on the trained weights."""
+    from nerf_meets_mlx_amd.dataset import synthetic
+    from nerf_meets_mlx_amd.engine.trainer import Trainer
+    from nerf_meets_mlx_amd.rendering import ray
+    H = W = 400
+    imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, 4, seed=0, device=DEV)
+    tr = Trainer(imgs, poses, K, N_rand=4096, n_depth_samples=64, N_importance=0, seed=4, device=DEV, precision=16)
+    losses = [float(tr.train_step()["loss_coarse"]) for _ in range(60)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-10:]) < 0.9 * np.mean(losses[:5]), (losses[:5], losses[-10:])
+    frame = tr.render_frame(poses[1])
+    assert tuple(frame.shape) == (H, W, 3) and torch.isfinite(frame).all()
+    mse = float(torch.mean((frame - imgs[1]) ** 2))
+    assert mse < 0.2, mse
+    idx = torch.arange(200 * W + 100, 200 * W + 164, device=DEV, dtype=torch.int64)           # 64 pixels of row 200
+    rays = ray.gen_rays(H, W, K, np.asarray(poses[1].cpu())[:3, :4], 2.0, 6.0, idx)
+    p = O.unflatten_params(O.NerfArch(), tr.coarse.params.detach().cpu())
+    want = O.render_rays(O.NerfArch(), p, rays.cpu(), 64, white_bkgd=True, emulate_bf16=True)
+    got = frame.reshape(-1, 3)[idx].cpu()
+    assert float((got - want["rgb_map"]).abs().max()) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ 1c: a15 index counts
+# bin indices that differ from the reference's own `inds` (the fixtures of tests/golden/make_golden.py: the reference's
+# sample_from_inverse_cdf_torch executed as it stands; sampling/__init__.py:114-143), per fixture, out of B x N_importance.
+# The kernel's normaliser is the float64 sum rounded once (csrc/sampling.hip), the reference's a float32 `torch.sum` whose order
+# depends on the host's SIMD width (1-ulp differences in s -> <= 2 ulp in the CDF): an index can differ only where u lies within
+# those ulps of a CDF knot.  On the committed fixtures NONE does, except in `signed` (negative weights, which raw2outputs cannot
+# produce: the near-zero weight sum cancels catastrophically, Q-list of DESIGN 2).
+A15_EXPECTED_MISMATCHES = {"const": 0, "zero": 0, "peaky": 0, "spike": 0, "jitter": 0, "small": 0}
+A15_SIGNED_BOUND = 8
+
+
+@pytest.mark.parametrize("tag", ["const", "zero", "peaky", "spike", "jitter", "small", "signed"])
+def test_importance_sampler_index_mismatch_count_per_fixture(tag):
+    from nerf_meets_mlx_amd import sampling
+    g = np.load(os.path.join(GOLD, "ref_inverse_cdf.npz"))
+    z, w, u, ref = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("z", "w", "u", "out"))
+    # the reference's integer outputs: recomputed from the reference's own CDF restated by the oracle, which reproduces the
+    # fixture's z_new BIT FOR BIT (asserted: so these ARE the indices the reference computed when the fixture was made)
+    z_ref, cdf_ref, inds_ref, _, _ = O.inverse_cdf_parts(z, w, u)
+    if not torch.equal(z_ref, ref):
+        pytest.skip("this host's torch.sum order differs from the fixture generator's (SIMD width): the reference's indices "
+                    "cannot be re-derived here")
+    _, _, cdf, inds = sampling.importance_sample(z.to(DEV), w.to(DEV), u.shape[-1], u=u.to(DEV), return_parts=True)
+    diff = int((inds.cpu() != inds_ref).sum())
+    ulps = float(((cdf.cpu() - cdf_ref).abs() / torch.finfo(torch.float32).eps).max())
+    print(f"a15 {tag}: {diff} of {inds.numel()} bin indices differ from the reference's; CDF max |diff| = {ulps:.2f} eps")
+    if tag == "signed":
+        assert diff <= A15_SIGNED_BOUND, diff
+    else:
+        assert diff == A15_EXPECTED_MISMATCHES[tag], (tag, diff)
+        assert torch.equal(inds.cpu(), inds_ref)
+
+
+def test_importance_sampler_index_mismatches_at_render_chunk_size():
+    """The same count at the size of one render chunk (32 768 rays x 128 uniforms = 4.2 M indices, weights from raw2outputs of
+    a random network): against the reference's arithmetic (oracle = torch-CPU float32, bit-identical to the reference on the
+    fixtures) at most 1e-4 of the indices may differ (measured: a few tens), every differing index by exactly one bin, and
+    only where u lies within 4 float32 ulps of a knot of the reference's CDF -- the ties the two summation orders break
+    differently.  z_new of all the others agrees to 2e-5."""
+    from nerf_meets_mlx_amd import sampling
+    B, n, N = 32768, 64, 128
+    g = torch.Generator().manual_seed(15)
+    z = torch.linspace(2.0, 6.0, n).expand(B, n).contiguous()
+    raw = torch.randn(B, n, 4, generator=g)
+    raw[..., 3] = raw[..., 3] * 3.0
+    rays_d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    _, _, _, w, _ = O.raw2outputs(raw, z, rays_d)
+    w = w.reshape(B, n, 1).clamp_min(0.0)                        # (the un-ReLU'd transmittance of Q10 can push a weight below 0)
+    u = torch.rand(B, N, generator=g)
+    z_ref, cdf_ref, inds_ref, _, _ = O.inverse_cdf_parts(z, w, u)
+    z_new, _, cdf, inds = sampling.importance_sample(z.to(DEV), w.to(DEV), N, u=u.to(DEV), return_parts=True)
+    z_new, cdf, inds = z_new.cpu(), cdf.cpu(), inds.cpu()
+    bad = inds != inds_ref
+    diff = int(bad.sum())
+    print(f"a15 render chunk: {diff} of {inds.numel()} bin indices differ from the reference's ({diff / inds.numel():.2e})")
+    assert diff <= 1e-4 * inds.numel(), diff
+    assert float((cdf - cdf_ref).abs().max()) <= 2.5e-7
+    if diff:
+        assert int((inds[bad] - inds_ref[bad]).abs().max()) == 1
+        rows = torch.nonzero(bad)[:, 0]
+        knots = cdf_ref[rows]                                      # [diff, n + 1]
+        dist = (knots - u[bad][:, None]).abs().min(dim=-1).values
+        assert float(dist.max()) <= 4 * torch.finfo(torch.float32).eps, float(dist.max())
+    np.testing.assert_allclose(z_new[~bad].numpy(), z_ref[~bad].numpy(), rtol=0, atol=2e-5)
+    assert float((z_new - z_ref).abs().max()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ the --gpus N line explains itself
+@pytest.mark.parametrize("extra", [[], ["--config", "ngp"]])
+def test_bench_two_rank_line_carries_the_communicator(extra):
+    """`bench.py --gpus 2` (self-spawned ranks; rehearsal transport gloo, both ranks on cuda:0 because RCCL refuses two ranks on
+    one device): the JSON line says which backend the ranks used, how many ranks ANSWERED an all-reduce before the timed region
+    (`world_size_seen`, asserted == --gpus inside bench.py), every rank's device, and the bytes the data path all-reduces per
+    step; value counts both ranks' rays."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NERF_DIST_BACKEND="gloo", NERF_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-rand", "256",
+           "--render-rays", "2048", "--hw", "64", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    c = d["comm"]
+    assert d["n_gpus"] == 2 and c["backend"] == "gloo" and c["world_size"] == 2 and c["world_size_seen"] == 2
+    assert [x["rank"] for x in c["devices"]] == [0, 1] and all(x["device"].startswith("cuda") for x in c["devices"])
+    assert c["allreduce_bytes_per_step"] > 0
+    if not extra:
+        assert c["allreduce_bytes_per_step"] == 2 * 595844 * 4 and c["collectives_per_step"] == 2
+        assert d["comm_ms_per_step"] is not None and d["comm_ms_per_step"] >= 0
+    assert len(d["rank_ms_per_step"]["ranks"]) == 2
+    assert abs(d["value"] - 2 * (256 + 2048) * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

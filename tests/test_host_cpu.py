@@ -58,7 +58,7 @@ def test_host_argument_validation_without_gpu():
     assert lib.nerf_mlp_acts_bytes(C.byref(arch), 65) == 8 * 167 * 1024          # 3 tiles, padded to a whole 8-tile super-tile
     assert lib.nerf_mlp_acts_bytes(C.byref(arch32), 65) == 3 * 2592 * 128         # fp32 stores: rows x 32 floats per tile (2528 activation rows + 64 of ReLU sign bits)
     assert lib.nerf_mlp_dz_bytes(C.byref(arch32), 65) == 3 * 2496 * 128 + 2048 * (4096 + 64) * 4      # + split-K partial blocks of dW
-    assert lib.nerf_get_option(b"mlp_precision") == -1 and lib.nerf_get_option(b"nonsense") == -1
+    assert lib.nerf_get_option(b"mlp_precision") == -2 ** 31 and lib.nerf_get_option(b"nonsense") == -2 ** 31
     assert lib.nerf_set_option(b"mlp_precision", 32) == -3                        # gone: NERF_E_UNSUPPORTED, with a pointer to the arch
     assert b"nerf_mlp_arch.precision" in lib.nerf_last_error()
     img = _native.MlpArch(8, 256, 40, 0, 4, 0, 3, 16)
@@ -283,3 +283,36 @@ def test_c_abi_header_compiles_as_c_and_library_links_from_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_check ok" in out.stdout
+
+
+def test_run_log_jsonl_format(tmp_path):
+    """engine/runlog.py (the reference keeps loss.item() per iteration and plots it, __test_nerf.py:298-299,314-322): one JSON
+    object per line, rank 0 only, appended across a resume; train records carry it / losses / PSNR / lr / whole-job rays/s
+    (evaluation renders excluded from the rate window), non-finite values become null."""
+    import json
+    import time
+    from nerf_meets_mlx_amd.engine import runlog
+    d = str(tmp_path / "exp")
+    log = runlog.RunLog(d, rank=0, world=2)
+    log.run(n_rand=1024, precision=22, resumed_from=None)
+    log.mark(0)
+    time.sleep(0.02)
+    r1 = log.train(100, 0.01, 0.001, 5e-4, 1024)
+    assert abs(r1["psnr_coarse"] - 20.0) < 1e-9 and abs(r1["psnr_fine"] - 30.0) < 1e-9
+    assert 0 < r1["rays_per_s"] <= 100 * 1024 * 2 / 0.02
+    log.eval(100, 23.5, 7, 5.0)                                       # a 5-second "render" does not count as training time
+    time.sleep(0.02)
+    r2 = log.train(200, float("nan"), None, 4e-4, 1024)
+    assert r2["loss_coarse"] is None and r2["loss_fine"] is None and r2["psnr_coarse"] is None
+    assert r2["rays_per_s"] is None or r2["rays_per_s"] > 0           # window minus the eval pause is <= 0 here -> null
+    # a second process-lifetime (resume) appends; other ranks write nothing
+    log2 = runlog.RunLog(d, rank=0, world=2)
+    log2.run(resumed_from="000200.npz")
+    runlog.RunLog(d, rank=1, world=2).train(300, 1.0, 1.0, 1e-4, 1024)
+    lines = [ln for ln in open(os.path.join(d, "log.jsonl")).read().splitlines() if ln]
+    recs = [json.loads(ln) for ln in lines]                           # every line is strict JSON (no NaN literals)
+    assert [r["kind"] for r in recs] == ["run", "train", "eval", "train", "run"] and recs == runlog.read(os.path.join(d, "log.jsonl"))
+    assert all("NaN" not in ln and "Infinity" not in ln for ln in lines)
+    assert set(recs[1]) == {"kind", "it", "loss_coarse", "loss_fine", "psnr_coarse", "psnr_fine", "lr", "rays_per_s", "elapsed_s"}
+    assert recs[2] == {"kind": "eval", "it": 100, "psnr": 23.5, "view": 7, "seconds": 5.0}
+    assert recs[0]["world_size"] == 2 and recs[4]["resumed_from"] == "000200.npz"

@@ -1,7 +1,7 @@
 """The fp32 kernels load their operands with asm loads and wait for them with their own counted s_waitcnt: hipcc must
 not touch a destination register before that wait (it parks such registers in AGPRs right behind the load as soon as the
 256 VGPRs run out -- measured on a version of the dW kernel with four VGPR sets in flight).  This test compiles
-csrc/mlp32.hip to ISA and scans it (tools/check_inflight_regs.py); CPU only (hipcc cross-compiles)."""
+csrc/mlp32.hip to ISA and scans it (csrc/check_inflight_regs.py); CPU only (hipcc cross-compiles)."""
 import os
 import shutil
 import subprocess

@@ -62,7 +62,11 @@ def _worker(rank, world, port, q):
     rows = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
     img = parallel.gather_rows_to_rank0(rows, B)
     ok_img = (img is None) if rank else bool(torch.equal(img[:, 0], torch.arange(B, dtype=torch.float32)))
-    q.put((rank, err, same, ok_img))
+    # --- the communicator describes itself (bench.py prints this in the --gpus N line): every rank answered the all-reduce
+    info = parallel.comm_info(allreduce_bytes_per_step=2 * 595844 * 4, collectives_per_step=2)
+    ok_info = (info["backend"] == "gloo" and info["world_size"] == world and info["world_size_seen"] == world
+               and [d["rank"] for d in info["devices"]] == list(range(world)) and info["allreduce_bytes_per_step"] == 4766752)
+    q.put((rank, err, same, ok_img and ok_info))
     dist.destroy_process_group()
 
 
@@ -93,3 +97,5 @@ def test_single_process_helpers():
     cover = [parallel.shard_range(10, r, 3) for r in range(3)]
     assert cover == [(0, 3), (3, 6), (6, 10)]
     assert parallel.gather_rows_to_rank0(t[:, None], 4).shape == (4, 1)
+    info = parallel.comm_info()
+    assert info["backend"] is None and info["world_size_seen"] == 1 and info["devices"] is None
