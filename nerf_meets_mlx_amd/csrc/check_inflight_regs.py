@@ -53,7 +53,9 @@ def scan(body, verbose=0):
         parts = t.replace(",", " ").split()
         op = parts[0]
         pend = set().union(*loads) if loads else set()
-        if op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
+        # a RETURNING atomic (sc0) is a load for this purpose: its destination VGPR is written when the data comes back
+        # (the pass-queue ticket of the ring kernels, mlp_ring.h)
+        if op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")) or (op.startswith(("global_atomic", "buffer_atomic", "flat_atomic")) and " sc0" in t):
             if "lds" in t:                       # LDS-DMA: counted by vmcnt, no register destination
                 loads.append(set())
                 continue

@@ -169,9 +169,10 @@ __device__ __forceinline__ void layer_fwd(WS& ws, int fbase, int bias_slot, cons
 // inputs and never stored, so every wave runs the same instruction stream (the ring needs that).
 // MODE 0: embedded rows;  MODE 1: rays + z with fused positional encodings
 template <int ST, int MODE, bool STORE, class WS>
-__device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane) {
+__device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane, PassQueue* pq = nullptr) {
   const int r = lane & 31, h = lane >> 5;
   bf16x8 pe[ST][4], dpe[ST][2];
+  if (pq) pq->ask(ws_wave(ws), lane);          // dynamic pass queue (mlp_ring.h): before this pass's input loads
 #pragma unroll
   for (int t = 0; t < ST; ++t) {
     int64_t tile = tile0 + t; if (tile >= ntiles) tile = ntiles - 1;
@@ -201,11 +202,18 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
       }
     }
   }
+  if (pq) pq->publish(ws_wave(ws));
   int bad[ST];                      // non-finite inputs of this lane's sample (mlp_frag.h: nonfinite_flags), used at the output store
 #pragma unroll
   for (int t = 0; t < ST; ++t)
+  {
     bad[t] = nonfinite_flags<32>(nonfinite_bits(pe[t][0]) | nonfinite_bits(pe[t][1]) | nonfinite_bits(pe[t][2]) | nonfinite_bits(pe[t][3]),
                                  nonfinite_bits(dpe[t][0]) | nonfinite_bits(dpe[t][1]));
+    // computed HERE, at the head of the pass.  Left to the scheduler, this arithmetic was sunk into the layer epilogues of the 2 x 64
+    // training forward, whose layer-0 ReLU sign words then lost bits (tests: test_weight_gradients_of_the_two_dw_launch_forms_agree
+    // [*-small-16]; the ISA of the interleaved form showed nothing wrong, the pinned form is bit-identical to the build without flags)
+    asm volatile("" : "+v"(bad[t]));
+  }
 #define store(slot0, t, frags, count) \
   do { if (STORE) { store_frags<count>(a.acts, tile0 + (t), a.astride, slot0, frags, r, h); ws.note_stores(count); } } while (0)
 #pragma unroll
@@ -371,15 +379,19 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_fwd_ring_kernel(FwdArgs a) {
   ring_load_bias(a.bias, L::BI_TOTAL, Ring::BIAS_OFF);
   __syncthreads();
   NERF_STAMP_BEGIN();
-  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+  PassQueue pq;                                         // dynamic pass queue (mlp_ring.h); a.queue == nullptr: static split
+  pq.init(a.queue, ws.lds0 + Ring::BIAS_OFF);
+  for (int64_t sp = blockIdx.x; sp < nsuper;) {
     int ln = lane;
     asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
     ws.new_pass();
-    fwd_tiles<1, MODE, STORE>(a, ws, sp * NW + wv, ntiles, ln);
+    fwd_tiles<1, MODE, STORE>(a, ws, sp * NW + wv, ntiles, ln, &pq);
     NERF_STAMP_PASS();
+    sp = pq.next(sp);
   }
   NERF_STAMP_END();
   ws.drain();                                           // the ring always runs 3 chunks ahead
+  pq.leave();
 }
 
 
@@ -617,7 +629,10 @@ __device__ __forceinline__ void fwd_tiles16(const FwdArgs& a, WS& ws, int64_t wt
   int bad[NS];                      // non-finite inputs of this lane's samples (mlp_frag.h: nonfinite_flags), used at the output store
 #pragma unroll
   for (int s = 0; s < NS; ++s)
+  {
     bad[s] = nonfinite_flags<16 | 32>(nonfinite_bits(pe[s][0]) | nonfinite_bits(pe[s][1]), nonfinite_bits(dpe[s][0]));
+    asm volatile("" : "+v"(bad[s]));          // at the head of the pass (see fwd_tiles)
+  }
   bf16x8 ha[NS][8], hb[NS][8];
   layer_fwd16<NS, 2, 16, true>(ws, L16::F_L0, 0, pe, ha, lane);
   layer_fwd16<NS, 8, 16, true>(ws, L16::F_L1 + 0 * 128, 256, ha, hb, lane);
@@ -714,21 +729,27 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd_ring16_kernel(FwdArgs a) {
     const int64_t first = (int64_t)blockIdx.x * NW + wv;
     pe16_all<NS>(a, pe16_setup(a.fr, lane >> 4), first < nwtiles ? first : nwtiles - 1, lane & 15, cur);
   }
-  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+  PassQueue pq;                                         // dynamic pass queue (mlp_ring.h); a.queue == nullptr: static split
+  pq.init(NERF_PE_HOIST ? nullptr : a.queue, ws.lds0 + RING_BIAS_OFF);      // (the hoisted-encoding build needs the next pass a pass early)
+  for (int64_t sp = blockIdx.x; sp < nsuper;) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     ws.new_pass();
     if (!NERF_PE_HOIST) {
       const int64_t wt = sp * NW + wv;
+      pq.ask(wv, ln);                                   // before this pass's input loads
       pe16_all<NS>(a, pe16_setup(a.fr, ln >> 4), wt < nwtiles ? wt : nwtiles - 1, ln & 15, cur);
+      pq.publish(wv);
     }
     fwd_tiles16<NS>(a, ws, sp * NW + wv, (sp + gridDim.x) * NW + wv, nwtiles, ln, cur);
     NERF_STAMP_PASS();
     NERF_STAMP2_PASS();
+    sp = pq.next(sp);
   }
   NERF_STAMP_END();
   NERF_STAMP2_END();
   ws.drain();
+  pq.leave();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -804,6 +825,7 @@ __device__ __forceinline__ void layer_bwd(WS& ws, int fbase, const bf16x8 (&in)[
 }
 
 struct BwdArgs {
+  unsigned* queue;       // dynamic pass queue slot of this launch, or nullptr (static split): mlp_ring.h
   const bf16x8* wb;
   const void* acts;
   const float* d_raw;    // [M,4]
@@ -813,8 +835,9 @@ struct BwdArgs {
 };
 
 template <int ST, class WS>
-__device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane) {
+__device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane, PassQueue* pq = nullptr) {
   const int r = lane & 31, h = lane >> 5;
+  if (pq) pq->ask(ws_wave(ws), lane);          // dynamic pass queue (mlp_ring.h): before this pass's input loads
   int64_t tile[ST];
   bool live[ST];
   bf16x8 zrgb[ST][1], zal[ST][1];
@@ -830,6 +853,7 @@ __device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile
     zrgb[t][0][0] = (__bf16)g.x; zrgb[t][0][1] = (__bf16)g.y; zrgb[t][0][2] = (__bf16)g.z;   // rows 0..2 (h == 0)
     zal[t][0][0] = (__bf16)g.w;                                                              // row 0
   }
+  if (pq) pq->publish(ws_wave(ws));
   // every ReLU mask of the pass is fetched here, so the chain itself issues no loads the compiler must wait for
   u32x4 mk[9][ST];
 #pragma unroll
@@ -892,15 +916,19 @@ __global__ void __launch_bounds__(64 * NW, 2) mlp_bwd_ring_kernel(BwdArgs a) {
   ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
   ws.wv = wv;
   ws.start(lane);
-  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+  PassQueue pq;                                         // dynamic pass queue (mlp_ring.h); a.queue == nullptr: static split
+  pq.init(a.queue, ws.lds0 + decltype(ws)::BIAS_OFF);
+  for (int64_t sp = blockIdx.x; sp < nsuper;) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     ws.new_pass();
-    bwd_tiles<1>(a, ws, sp * NW + wv, ntiles, ln);
+    bwd_tiles<1>(a, ws, sp * NW + wv, ntiles, ln, &pq);
     // the pass ends inside the last chunk (1100 is not a multiple of the chunk): nothing else to do, the next pass starts
     // at a chunk boundary again because fragment indices restart at 0
+    sp = pq.next(sp);
   }
   ws.drain();
+  pq.leave();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1149,7 +1177,8 @@ __device__ __forceinline__ void fwd_tiles_img(const ImgArgs& a, WS& ws, int64_t 
   bf16x8 xin[ST][3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) xin[0][ks] = row_frag(a.x + m * LI::CIN, ks, h, LI::CIN);
-  const int bad = nonfinite_flags<32>(nonfinite_bits(xin[0][0]) | nonfinite_bits(xin[0][1]) | nonfinite_bits(xin[0][2]), 0u);
+  int bad = nonfinite_flags<32>(nonfinite_bits(xin[0][0]) | nonfinite_bits(xin[0][1]) | nonfinite_bits(xin[0][2]), 0u);
+  asm volatile("" : "+v"(bad));               // at the head of the pass (see fwd_tiles)
   if (STORE) { store_frags<3>(a.acts, tile0, a.astride, LI::A_X, xin[0], r, h); ws.note_stores(3); }
   bf16x8 ha[ST][16], hb[ST][16];
   u32x4 mk[ST];
@@ -1395,7 +1424,8 @@ __global__ void __launch_bounds__(512) mlp_small_fwd_kernel(SmallArgs a) {
       xin[0][0] = row_frag(row, 0, h, LN::CPOS); xin[0][1] = row_frag(row, 1, h, LN::CPOS);
       din[0][0] = row_frag(row + LN::CPOS, 0, h, LN::CDIR);
     }
-    const int bad = nonfinite_flags<32>(nonfinite_bits(xin[0][0]) | nonfinite_bits(xin[0][1]), nonfinite_bits(din[0][0]));
+    int bad = nonfinite_flags<32>(nonfinite_bits(xin[0][0]) | nonfinite_bits(xin[0][1]), nonfinite_bits(din[0][0]));
+    asm volatile("" : "+v"(bad));         // at the head of the tile (see fwd_tiles)
 #define SINK(slot0) FragSink<STORE>{a.acts, tile0, a.astride, slot0, r, h}
 #define MASK_STORE(layer) do { if (STORE) *reinterpret_cast<u32x4*>(frag_ptr(a.acts, tile0, a.astride, LN::A_MASK + (layer), r, h)) = mk[0]; } while (0)
     if (STORE) { store_frags<2>(a.acts, tile0, a.astride, LN::A_X, xin[0], r, h); store_frags<1>(a.acts, tile0, a.astride, LN::A_DX, din[0], r, h); }
@@ -1512,6 +1542,7 @@ static int g_mlp_variant = 0;   // 0: auto, 1: ST=1 via L1, 2: ST=2 via L1, 3: L
                                 // 4: ring, 16x16x32 MFMA, 8 waves x 32 samples (inference only), 5: same, 4 waves x 64 samples
 static int g_ring_wgs = 0;       // persistent workgroups of the ring kernels; 0 = one per CU of the current device
 static int g_ngp_ray_major = 1;   // A/B knob: fused configs[4] inference query walks (32 rays x 1 depth) tiles (1) or (1 ray x 32 depths) tiles (0)
+int g_pass_queue = 1;               // "pass_queue": 1 (default) the persistent ring kernels take their passes from a device-wide counter (mlp_ring.h), 0 = static split
 static int g_ring_split = 1;     // training ring kernels: 1 = one 8-wave workgroup per CU (128 KiB ring), 2 = two 4-wave workgroups (64 KiB rings)
 // precision of a model = nerf_mlp_arch.precision (ABI 3): 16 (or 0) bf16 MFMA operands with fp32 accumulate, 32 the fp32
 // reference-precision kernels of mlp32.hip.  Nothing process-wide: two models of different precision can be packed,
@@ -1603,6 +1634,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "dw16_variant")) { g_dw16_variant = value < 0 ? 0 : value > 3 ? 3 : value; return NERF_OK; }
   if (!strcmp(key, "dw_private_tiles")) { g_dw_private = value < 0 ? 0 : value > 4 ? 4 : value; return NERF_OK; }
   if (!strcmp(key, "dw_ring_cap")) { g_dw_ring_cap = value < 2 ? 2 : value > 16 ? 16 : value; return NERF_OK; }
+  if (!strcmp(key, "pass_queue")) { g_pass_queue = value ? 1 : 0; return NERF_OK; }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -1622,6 +1654,7 @@ extern "C" int nerf_get_option(const char* key) {
   if (!strcmp(key, "dw_job_mask")) return g_dw_job_mask;
   if (!strcmp(key, "dw_private_tiles")) return g_dw_private;
   if (!strcmp(key, "dw_ring_cap")) return g_dw_ring_cap;
+  if (!strcmp(key, "pass_queue")) return g_pass_queue;
   return NERF_OPTION_UNKNOWN;
 }
 
@@ -1715,6 +1748,7 @@ template <int MODE>
 static int launch_fwd(const void* packed, const float* x, const float* rays, const float* z, int64_t M, int n,
                       int freq_mode, float* out, void* acts, void* stream) {
   FwdArgs a;
+  a.queue = nullptr;
   const char* base = static_cast<const char*>(packed);
   a.wf = reinterpret_cast<const bf16x8*>(base);
   a.bias = reinterpret_cast<const float*>(base + (size_t)(L::F_TOTAL + L::B_PADDED) * 1024);
@@ -1731,12 +1765,14 @@ static int launch_fwd(const void* packed, const float* x, const float* rays, con
     static DevOnce once16;
     once16.run([&] { ensure_lds(mlp_fwd_ring16_kernel<8, 2>, RING16_LDS_BYTES); ensure_lds(mlp_fwd_ring16_kernel<4, 4>, RING16_LDS_BYTES); });
     FwdArgs a16 = a;
+    a16.queue = passq_slot();
     a16.wf = reinterpret_cast<const bf16x8*>(base + L::F16_OFFSET);
     if (variant == 4) hipLaunchKernelGGL((mlp_fwd_ring16_kernel<8, 2>), g, dim3(512), RING16_LDS_BYTES, s, a16);
     else hipLaunchKernelGGL((mlp_fwd_ring16_kernel<4, 4>), g, dim3(256), RING16_LDS_BYTES, s, a16);
     return check_launch("mlp forward (ring, 16x16x32)");
   }
   if (variant >= 3 && MODE == 1) {
+    a.queue = passq_slot();
     if (acts && g_ring_split == 2) {                      // two 4-wave workgroups per CU, each with its own 64 KiB ring
       const int64_t nsuper = (ntiles + SPLIT_NW - 1) / SPLIT_NW;
       const int64_t wgs = 2 * (int64_t)ring_wgs();
@@ -2050,11 +2086,13 @@ static int mlp_backward_impl(const nerf_mlp_arch* arch, const void* packed, cons
   }
   // ---- 1. dZ chain
   BwdArgs b;
+  b.queue = nullptr;
   b.wb = reinterpret_cast<const bf16x8*>(static_cast<const char*>(packed) + (size_t)L::F_TOTAL * 1024);
   b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz; b.astride = astride16(); b.zstride = zstride16();
   const int variant = g_mlp_variant == 0 ? 3 : g_mlp_variant;
   if (split) {
   } else if (variant >= 3) {
+    b.queue = passq_slot();
     if (g_bwd_stage != 2 && g_ring_split == 2) {
       const int64_t nsuper = (ntiles + SPLIT_NW - 1) / SPLIT_NW;
       const int64_t wgs = 2 * (int64_t)ring_wgs();

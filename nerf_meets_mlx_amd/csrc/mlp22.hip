@@ -286,9 +286,10 @@ __device__ __forceinline__ void head22(WS& ws, int pbase, int bias_slot, const u
 // All 12 layers for the wave's 32 samples (sample tiles 2 wtile0, 2 wtile0 + 1 of 16).  Waves past the end compute on
 // clamped inputs and store nothing, so every wave of the workgroup runs the same instruction stream (the ring needs that).
 template <int MODE, class WS>
-__device__ __forceinline__ void tiles22(const FwdArgs& a, WS& ws, int64_t wtile0, int64_t nwtiles, int lane) {
+__device__ __forceinline__ void tiles22(const FwdArgs& a, WS& ws, int64_t wtile0, int64_t nwtiles, int lane, PassQueue& pq) {
   const int c = lane & 15, g = lane >> 4;
   u32x4 peh[2][2], pel[2][2], dph[2][1], dpl[2][1];
+  pq.ask(ws.wv, lane);                    // the workgroup's next pass: asked for before this pass's input loads (mlp_ring.h)
   {
     const int64_t wt = wtile0 < nwtiles ? wtile0 : nwtiles - 1;
     const Pe22 q = pe22_setup(a.fr, g);
@@ -314,6 +315,7 @@ __device__ __forceinline__ void tiles22(const FwdArgs& a, WS& ws, int64_t wtile0
       }
     }
   }
+  pq.publish(ws.wv);
   u32x4 hah[2][8], hal[2][8], hbh[2][8], hbl[2][8];
   layer22<2, 16, true>(ws, L16::F_L0, 0, peh, pel, hah, hal, lane);
   layer22<8, 16, true>(ws, L16::F_L1 + 0 * 128, 256, hah, hal, hbh, hbl, lane);
@@ -374,15 +376,19 @@ __global__ void __launch_bounds__(64 * NW22) mlp22_fwd_kernel(FwdArgs a) {
   ring_load_bias(a.bias, BIAS_FLOATS);
   __syncthreads();
   NERF_STAMP2_LOOP();
-  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+  PassQueue pq;                           // dynamic pass queue (mlp_ring.h); a.queue == nullptr: static split
+  pq.init(a.queue, ws.lds0 + RING_BIAS_OFF);
+  for (int64_t sp = blockIdx.x; sp < nsuper;) {
     int ln = lane;
     asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
     ws.new_pass();
-    tiles22<MODE>(a, ws, sp * NW22 + wv, nwtiles, ln);
+    tiles22<MODE>(a, ws, sp * NW22 + wv, nwtiles, ln, pq);
     NERF_STAMP2_PASS();
+    sp = pq.next(sp);
   }
   NERF_STAMP2_END();
   ws.drain();                             // the ring always runs 3 chunks ahead
+  pq.leave();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -398,6 +404,7 @@ int pack(const float* params, void* packed22, hipStream_t s) {
 int forward(const void* packed22, const float* x, const float* rays, const float* z, int64_t M, int n, int freq_mode,
             float* out, int persistent_wgs, hipStream_t s) {
   FwdArgs a;
+  a.queue = passq_slot();
   const char* base = static_cast<const char*>(packed22);
   a.wf = reinterpret_cast<const bf16x8*>(base);
   a.bias = reinterpret_cast<const float*>(base + (size_t)F_PADDED * 1024);

@@ -169,9 +169,14 @@ __device__ __forceinline__ unsigned nonfinite_bits(const bf16x8& f) {
 // select the sample -- 32 in the 32x32x16 chains, 16 | 32 in the 16x16x32 chains)
 template <int XOR_MASKS>
 __device__ __forceinline__ int nonfinite_flags(unsigned pos_bits, unsigned dir_bits) {
-  int f = (pos_bits ? 1 : 0) | (dir_bits ? 2 : 0);
-  if (XOR_MASKS & 16) f |= __shfl_xor(f, 16);
-  if (XOR_MASKS & 32) f |= __shfl_xor(f, 32);
+  // wave ballots + a per-lane shift: scalar compares and VALU only (a ds_bpermute shuffle here cost the 2 x 64 training forward its
+  // layer-0 ReLU sign words -- tests/test_gpu_round5.py::test_weight_gradients_of_the_two_dw_launch_forms_agree[*-small-16])
+  const unsigned long long mp = __ballot(pos_bits != 0u), md = __ballot(dir_bits != 0u);
+  const int lane = (int)__lane_id();
+  int f = 0;
+#pragma unroll
+  for (int x = 0; x < 64; x += 16)
+    if ((x & ~XOR_MASKS) == 0) f |= (int)((mp >> (lane ^ x)) & 1ull) | ((int)((md >> (lane ^ x)) & 1ull) << 1);
   return f;
 }
 // [rgb, alpha] of a flagged sample: position -> all NaN; direction only -> rgb NaN, alpha as computed (it does not depend on it)

@@ -2,6 +2,7 @@
 // LDS-DMA helpers, the LDS weight ring (RingW) and the argument block of the forward kernels.
 #pragma once
 #include "common.h"
+#include <atomic>
 
 #ifndef NERF_SPREAD_DMA
 #define NERF_SPREAD_DMA 1     // ring refill: one DMA per quarter chunk interval instead of a burst of 4
@@ -279,13 +280,87 @@ struct Stamp2 {
 #endif
 
 template <class WS> struct is_ring { static constexpr bool value = false; };
+// wave id of a ring source (the pass queue's wave 0); the L1 / LDS-resident sources never run a queue
+template <class WS> __device__ __forceinline__ int ws_wave(const WS&) { return 0; }
+template <int N, int T, int G, int W, int C, int S, bool R> __device__ __forceinline__ int ws_wave(const RingW<N, T, G, W, C, S, R>& w) { return w.wv; }
 template <int N, int T, int G, int W, int C, int S, bool R> struct is_ring<RingW<N, T, G, W, C, S, R>> { static constexpr bool value = true; };
 
 template <class WS>
 __device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }
 
 
+// ------------------------------------------------------------------------------------------
+// Dynamic pass queue of the persistent ring kernels (round 6; tools/probe_launch_profile.py).
+// With a static split (pass = blockIdx.x + k gridDim.x) a launch ends when the slowest XCD has finished its share: the eight XCDs of
+// an MI355X hold different clocks under load (stamps: all 32 workgroups of an XCD end within 10 us of one another, the XCDs 3-8 %
+// apart -- which ones are slow changes with what ran before), i.e. the tail of a launch is 130-330 us of 5-15 ms.  Here a
+// workgroup runs pass blockIdx.x first and takes every further pass from ONE device-wide counter.
+//   * ask(): lane 0 of wave 0 asks for the workgroup's NEXT pass with a returning atomic at the very head of the current pass, BEFORE
+//     the pass's own input loads.  Those loads are waited for at the head anyway (the one vmcnt(0) a pass has always had: hipcc does
+//     not see the ring's LDS-DMAs and waits for its own loads with a full drain), and the atomic, being older, is covered by the
+//     same wait: no additional drain.  (A first form issued the atomic mid-pass from inline asm into a sentinel-primed VGPR --
+//     tools/ticket_probe.hip; as an `if` it split the pass into two basic blocks, hipcc sank the direction encodings across the
+//     split and waited for the rays' loads mid-pass: one more drain per pass.  This form needs no asm atomic and no scanner.)
+//   * publish(): behind the first use of the inputs, wave 0 writes the next pass index to one of TWO LDS words (pass parity), branch-free
+//     (the EXEC mask selects wave 0 or nobody); next(): at the end of the pass every wave reads it.  The >= 37 chunk barriers of the
+//     ring between the two order write and read; the parity keeps wave 0's write of the following pass off a word a slower wave has
+//     not read yet.  All LDS traffic is inline asm: through a C++ pointer hipcc loses the address space and emits flat_store /
+//     flat_load + vmcnt(0).
+//   * The counter lives in a slot of a small device array (PASSQ_SLOTS per translation unit and device, taken round-robin by the
+//     host: launches in flight at the same time never share one); the last workgroup to leave a launch clears its slot.
+//   * nerf_set_option("pass_queue", 0) = static split (queue pointer null): same kernel, same results -- which workgroup computes a
+//     pass changes nothing a pass computes.
+// ------------------------------------------------------------------------------------------
+constexpr int PASSQ_SLOTS = 256;
+constexpr int PASSQ_LDS_OFF_FLOAT = 2558;      // two LDS words: the last two floats of the 2560-float bias area (every stream's bias count is <= 2496)
+static __device__ unsigned g_passq[PASSQ_SLOTS][4];
+struct PassQueue {
+  unsigned* q;            // [0] passes handed out, [1] workgroups that have left; nullptr: static split
+  unsigned lds_words;     // LDS byte address of the two words
+  unsigned parity;        // of the pass being executed (wave-uniform)
+  unsigned t;             // lane 0 of wave 0: the returning atomic's destination
+  __device__ __forceinline__ void init(unsigned* queue, unsigned lds_bias_addr) { q = queue; lds_words = lds_bias_addr + 4 * PASSQ_LDS_OFF_FLOAT; parity = 0u; t = 0u; }
+  __device__ __forceinline__ void ask(int wv, int lane) {
+    t = 0u;
+    if (q && wv == 0 && lane == 0) t = atomicAdd(q, 1u);
+  }
+  __device__ __forceinline__ void publish(int wv) {
+    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((q && wv == 0) ? 1 : 0);
+    const unsigned v = gridDim.x + (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, 0\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(lds_words + 4u * parity), "v"(v), "s"(mask) : "memory");
+  }
+  __device__ __forceinline__ int64_t next(int64_t sp) {
+    if (!q) return sp + gridDim.x;
+    unsigned r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_words + 4u * parity) : "memory");
+    parity ^= 1u;
+    return (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)r);
+  }
+  // end of the kernel: the last workgroup to leave clears the slot for its next user
+  __device__ __forceinline__ void leave() const {
+    if (q && threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&q[1], 1u) == gridDim.x - 1) { q[0] = 0u; q[1] = 0u; }
+    }
+  }
+};
+// host: the queue slot of the next launch of this translation unit on the current device (nullptr: static split)
+extern int g_pass_queue;                       // mlp.hip: nerf_set_option("pass_queue")
+static inline unsigned* passq_slot() {
+  if (!g_pass_queue) return nullptr;
+  static unsigned* base[64] = {};
+  static DevOnce once;
+  static std::atomic<unsigned> next{0};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+  once.run([&] { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_passq)) == hipSuccess) base[d] = static_cast<unsigned*>(p); });
+  return base[d] ? base[d] + 4 * (next.fetch_add(1u) % PASSQ_SLOTS) : nullptr;
+}
+
 struct FwdArgs {
+  unsigned* queue;       // dynamic pass queue slot of this launch, or nullptr (static split)
   const bf16x8* wf;      // forward fragment stream
   const float* bias;     // bias slots
   const float* x;        // MODE 0: [M,90]

@@ -103,9 +103,10 @@ __device__ __forceinline__ void pe_frag(const float (&x)[3], const float (&fr)[N
 // the padding tiles of the workspace and write no output, so every wave runs the same instruction stream (the ring needs it).
 // MODE 0: embedded rows;  MODE 1: rays + z with fused positional encodings
 template <int MODE, class WS>
-__device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane) {
+__device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane, PassQueue& pq) {
   const int r = lane & 31, h = lane >> 5;
   bf16x8 peh[4], pel[4], dph[2], dpl[2];
+  pq.ask(ws.wv, lane);                    // dynamic pass queue (mlp_ring.h): before this pass's input loads
   {
     const int64_t tile = tile0 < ntiles ? tile0 : ntiles - 1;
     int64_t m = tile * 32 + r; if (m >= a.M) m = a.M - 1;
@@ -127,6 +128,7 @@ __device__ __forceinline__ void fwd_tiles(const FwdArgs& a, WS& ws, int64_t tile
       pe_frag<0, 27, 4>(d, a.fr.dir, h, dph[0], dpl[0]); pe_frag<1, 27, 4>(d, a.fr.dir, h, dph[1], dpl[1]);
     }
   }
+  pq.publish(ws.wv);
   store_frags<4>(a.acts, tile0, a.astride, L::A_PE, peh, r, h); store_frags<4>(a.acts, tile0, a.astride, A_LO + L::A_PE, pel, r, h);
   store_frags<2>(a.acts, tile0, a.astride, L::A_DPE, dph, r, h); store_frags<2>(a.acts, tile0, a.astride, A_LO + L::A_DPE, dpl, r, h);
 
@@ -219,17 +221,22 @@ __global__ void __launch_bounds__(64 * NW) s16_fwd_kernel(FwdArgs a) {
   ws.start(lane);
   ring_load_bias(a.bias, L::BI_TOTAL, FwdRing::BIAS_OFF);
   __syncthreads();
-  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+  PassQueue pq;                           // dynamic pass queue (mlp_ring.h); a.queue == nullptr: static split
+  pq.init(a.queue, ws.lds0 + FwdRing::BIAS_OFF);
+  for (int64_t sp = blockIdx.x; sp < nsuper;) {
     int ln = lane;
     asm volatile("" : "+v"(ln));          // lane-derived values are recomputed per pass, not hoisted and spilled
     ws.new_pass();
-    fwd_tiles<MODE>(a, ws, sp * NW + wv, ntiles, ln);
+    fwd_tiles<MODE>(a, ws, sp * NW + wv, ntiles, ln, pq);
+    sp = pq.next(sp);
   }
   ws.drain();                             // the ring always runs 3 chunks ahead
+  pq.leave();
 }
 
 
 struct BwdArgs {
+  unsigned* queue;       // dynamic pass queue slot of this launch, or nullptr (static split): mlp_ring.h
   const bf16x8* wb;
   const void* acts;
   const float* d_raw;    // [M,4]
@@ -239,9 +246,10 @@ struct BwdArgs {
 };
 
 template <class WS>
-__device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane) {
+__device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile0, int64_t ntiles, int lane, PassQueue& pq) {
   const int r = lane & 31, h = lane >> 5;
   const bool live = tile0 < ntiles;
+  pq.ask(ws.wv, lane);                    // dynamic pass queue (mlp_ring.h): before this pass's input loads
   const int64_t tile = live ? tile0 : ntiles - 1;
   bf16x8 zrh[1], zrl[1], zah[1], zal[1];
   {
@@ -252,6 +260,7 @@ __device__ __forceinline__ void bwd_tiles(const BwdArgs& a, WS& ws, int64_t tile
     split_slots<8>(vr, zrh, zrl);                         // rows 0..2 (h == 0)
     split_slots<8>(va, zah, zal);                         // row 0
   }
+  pq.publish(ws.wv);
   // every ReLU mask of the pass is fetched here, so the chain itself issues no loads the compiler must wait for
   u32x4 mk[9];
 #pragma unroll
@@ -291,15 +300,19 @@ __global__ void __launch_bounds__(64 * NW) s16_bwd_kernel(BwdArgs a) {
   ws.lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring_smem));
   ws.wv = wv;
   ws.start(lane);
-  for (int64_t sp = blockIdx.x; sp < nsuper; sp += gridDim.x) {
+  PassQueue pq;                           // dynamic pass queue (mlp_ring.h); a.queue == nullptr: static split
+  pq.init(a.queue, ws.lds0 + BwdRing::BIAS_OFF);
+  for (int64_t sp = blockIdx.x; sp < nsuper;) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
     ws.new_pass();
-    bwd_tiles(a, ws, sp * NW + wv, ntiles, ln);
+    bwd_tiles(a, ws, sp * NW + wv, ntiles, ln, pq);
     // the pass ends inside the last chunk (2200 is not a multiple of 32): the next pass starts at a chunk boundary again
     // because fragment indices restart at 0
+    sp = pq.next(sp);
   }
   ws.drain();
+  pq.leave();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -697,6 +710,7 @@ int pack(const float* params, void* packed_s16, hipStream_t s) {
 int forward(const void* packed_s16, const float* bias_slots, const float* x, const float* rays, const float* z, int64_t M,
             int n, int freq_mode, float* out, void* acts, int64_t astride16, int persistent_wgs, hipStream_t s) {
   FwdArgs a;
+  a.queue = passq_slot();
   a.wf = reinterpret_cast<const bf16x8*>(packed_s16);
   a.bias = bias_slots;
   a.x = x; a.rays = rays; a.z = z; a.M = M; a.n = n; a.out = out; a.acts = acts; a.astride = astride16;
@@ -717,6 +731,7 @@ int forward(const void* packed_s16, const float* bias_slots, const float* x, con
 int backward_chain(const void* packed_s16, const void* acts, const float* d_raw, int64_t M, void* dz, int64_t astride16,
                    int64_t zstride16, int persistent_wgs, hipStream_t s) {
   BwdArgs b;
+  b.queue = passq_slot();
   b.wb = reinterpret_cast<const bf16x8*>(static_cast<const char*>(packed_s16) + (size_t)F_FRAGS * 1024);
   b.acts = acts; b.d_raw = d_raw; b.M = M; b.dz = dz; b.astride = astride16; b.zstride = zstride16;
   const int64_t nsuper = ((M + 31) / 32 + NW - 1) / NW;

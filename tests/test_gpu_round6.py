@@ -298,7 +298,7 @@ def test_importance_sampler_index_mismatches_at_render_chunk_size():
     a random network): against the reference's arithmetic (oracle = torch-CPU float32, bit-identical to the reference on the
     fixtures) at most 1e-4 of the indices may differ (measured: a few tens), every differing index by exactly one bin, and
     only where u lies within 4 float32 ulps of a knot of the reference's CDF -- the ties the two summation orders break
-    differently.  z_new of all the others agrees to 2e-5."""
+    differently.  z_new of the others agrees to 2e-5 for all but < 1e-4 of them (narrow bins amplify the CDF's ulps), 1e-3 at worst."""
     from nerf_meets_mlx_amd import sampling
     B, n, N = 32768, 64, 128
     g = torch.Generator().manual_seed(15)
@@ -323,7 +323,10 @@ def test_importance_sampler_index_mismatches_at_render_chunk_size():
         knots = cdf_ref[rows]                                      # [diff, n + 1]
         dist = (knots - u[bad][:, None]).abs().min(dim=-1).values
         assert float(dist.max()) <= 4 * torch.finfo(torch.float32).eps, float(dist.max())
-    np.testing.assert_allclose(z_new[~bad].numpy(), z_ref[~bad].numpy(), rtol=0, atol=2e-5)
+    # z_new = z_from + (u - cdf_from) / (cdf_to - cdf_from) (z_to - z_from): a 2-ulp CDF difference is amplified by 1 / bin mass,
+    # so a handful of samples in bins of mass ~1e-4 move by a few 1e-5 (measured: 33 of 4.2 M beyond 2e-5, max 4.9e-5)
+    dz = (z_new - z_ref).abs()[~bad]
+    assert int((dz > 2e-5).sum()) <= 1e-4 * dz.numel(), int((dz > 2e-5).sum())
     assert float((z_new - z_ref).abs().max()) < 1e-3
 
 
@@ -353,3 +356,45 @@ def test_bench_two_rank_line_carries_the_communicator(extra):
         assert d["comm_ms_per_step"] is not None and d["comm_ms_per_step"] >= 0
     assert len(d["rank_ms_per_step"]["ranks"]) == 2
     assert abs(d["value"] - 2 * (256 + 2048) * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+# ------------------------------------------------------------------------------------------------ dynamic pass queue
+@pytest.mark.parametrize("precision", [22, 16])
+def test_pass_queue_changes_no_result(precision):
+    """The persistent ring kernels take their passes from a device-wide counter ("pass_queue" 1, the default: csrc/mlp_ring.h) instead of
+    a static split: which workgroup computes a pass changes nothing a pass computes.  Inference and training forward, stored
+    activations' consequences (the full parameter gradient) are bit-identical with the queue on and off, for ragged sizes and for
+    more passes than workgroups; 600 back-to-back launches walk twice through the 256 queue slots of a translation unit and leave
+    every slot clear (each result equals the first)."""
+    from nerf_meets_mlx_amd import _native
+    lib = _native.lib()
+    m, arch, p = _view_model(precision, seed=2)
+    g = torch.Generator().manual_seed(8)
+    res = {}
+    try:
+        for v in (1, 0, 1):
+            _native.check(lib.nerf_set_option(b"pass_queue", v))
+            assert lib.nerf_get_option(b"pass_queue") == v
+            out = []
+            for B, n in ((1, 1), (5, 7), (700, 64), (3000, 192)):               # 1 ... 4500 passes of 128 / 256 samples
+                gg = torch.Generator().manual_seed(B)
+                rays = _rays(B, B).to(DEV)
+                z = torch.sort(torch.rand(B, n, generator=gg) * 4 + 2, -1).values.to(DEV)
+                d_raw = torch.randn(B, n, 4, generator=gg).to(DEV)
+                inf = m.query(rays, z).clone()
+                trn = m.query(rays, z, train=True).clone()
+                grads = m.backward(d_raw).clone()
+                out += [inf, trn, grads]
+            if v in res:
+                assert all(torch.equal(a, b) for a, b in zip(res[v], out)), "not reproducible"
+            res[v] = out
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b)
+        _native.check(lib.nerf_set_option(b"pass_queue", 1))
+        rays = _rays(300, 1).to(DEV)
+        z = torch.linspace(2.0, 6.0, 64, device=DEV).expand(300, 64).contiguous()
+        first = m.query(rays, z).clone()
+        for i in range(600):
+            assert torch.equal(m.query(rays, z), first), i
+    finally:
+        _native.check(lib.nerf_set_option(b"pass_queue", 1))

@@ -73,13 +73,55 @@ def report(name, ms, st):
                                                                                for x in range(8) if (xcc == x).any()))
 
 
+def step_context(B):
+    """The launches as the bench's own step runs them, in steady state: 12 full steps (training step at N_rand 4096 + render chunk:
+    coarse pass, compositing, importance sampling, fine pass), then one more step that stops right behind the launch of interest --
+    its stamps are then the last ones the kernel wrote."""
+    from nerf_meets_mlx_amd.dataset import synthetic
+    from nerf_meets_mlx_amd.engine.trainer import Trainer
+    from nerf_meets_mlx_amd.rendering import ray
+    H = W = 800
+    imgs, poses, rposes, hwf, K = synthetic.make_dataset(H, W, 4, seed=0, device=dev)
+    ridx = torch.arange(0, B, device=dev, dtype=torch.int64)
+    rrays = ray.gen_rays(H, W, K, rposes[40][:3, :4], 2.0, 6.0, ridx)
+    for prec, fn in ((22, "nerf_debug_stamps2_mlp22"), (16, "nerf_debug_stamps2_ring16")):
+        tr = Trainer(imgs, poses, K, N_rand=4096, n_depth_samples=64, N_importance=128, seed=4, device=dev, chunk=B, precision=prec)
+
+        def render_chunk(stop_after_coarse, timed):
+            z = sampling.sample_coarse(rrays, 64)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if stop_after_coarse:
+                e0.record(); raw = tr.coarse.query(rrays, z); e1.record()
+                return e0, e1
+            raw = tr.coarse.query(rrays, z)
+            _, _, _, w, _ = render.composite(raw, z, rrays, 0.0, True)
+            u = torch.rand(B, 128, device=dev, generator=tr.gen)
+            _, zf = sampling.importance_sample(z, w, 128, u=u)
+            e0.record(); raw = tr.fine.query(rrays, zf); e1.record()
+            render.composite(raw, zf, rrays, 0.0, True, need_weights=False)
+            return e0, e1
+        for which in ("coarse", "fine"):
+            for _ in range(12):
+                tr.train_step()
+                render_chunk(False, False)
+            tr.train_step()
+            e0, e1 = render_chunk(which == "coarse", True)
+            torch.cuda.synchronize()
+            n = 64 if which == "coarse" else 192
+            nwg = min(256, (B * n + 127) // 128)
+            report(f"precision {prec} {fn.split('_')[-1]} render {which} pass {B} x {n} samples inside the bench's step (steady state)",
+                   e0.elapsed_time(e1), stamps(fn, nwg))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--context", choices=["hot", "bench"], default="hot")
+    ap.add_argument("--context", choices=["hot", "bench", "step"], default="hot")
     ap.add_argument("--rays", type=int, default=32768)
     a = ap.parse_args()
     torch.manual_seed(0)
     B = a.rays
+    if a.context == "step":
+        return step_context(B)
     o = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1) * 4
     d = -o / 4 + 0.2 * torch.randn(B, 3, device=dev)
     r = torch.zeros(B, 11, device=dev); r[:, :3] = o; r[:, 3:6] = d; r[:, 6] = 2; r[:, 7] = 6
