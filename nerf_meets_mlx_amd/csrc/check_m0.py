@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--no-scratch", action="store_true", help="also fail when a scanned kernel contains scratch (spill) instructions: "
                     "the one-wave-per-SIMD kernels are sized to the 512-register file; a change that tips hipcc into scratch costs "
                     "them a factor (round 4: +3 ms on the split-bf16 chain kernel) without failing any test")
+    ap.add_argument("--allow-scratch", nargs=2, action="append", default=[], metavar=("KERNEL_SUBSTRING", "MAX"),
+                    help="a kernel that may hold up to MAX scratch instructions (an opt-in, experimental variant whose spills were looked at)")
     a = ap.parse_args()
     text = open(a.asm).read()
     bad, seen = 0, 0
@@ -47,7 +49,8 @@ def main():
                     print(f"    {name}: compiler-side M0 use: {ln}")
         spills = sum(1 for ln in body if ln.startswith("scratch_")) if a.no_scratch else 0
         print(f"{name}: {ours} LDS-DMA M0 writes, {other} other M0 uses" + (f", {spills} scratch instructions" if a.no_scratch else ""))
-        bad += other + spills
+        allowed = max([int(n) for k, n in a.allow_scratch if k in name] or [0])
+        bad += other + (spills if spills > allowed else 0)
     if not seen:
         print("no kernel matched", file=sys.stderr)
         return 2

@@ -1534,6 +1534,7 @@ static int g_bwd_stage = 0;    // diagnostic: 0 chain + dW, 1 chain only, 2 dW o
 static int g_dw_ring_cap = 8;  // "dw_ring_cap": most stages the 16-wave split-bf16 dW kernel's LDS ring may hold (2 .. 16)
 static int g_dw_private = 4;   // "dw_private_tiles": split-bf16 dW jobs of at most this many output tiles run as sixteen wave-private pipelines (0 = off)
 static int g_dw16_variant = 1;  // "dw16_variant": bf16 weight gradients: 1 (default) = 256 x 256 jobs on mlp_dww.hip's kernel, tiny-job lists on mlp_s16.hip's, the rest on mlp_dw_kernel; 0 = every job on mlp_dw_kernel; 2 = as 1 without the tiny-job rule; 3 = as 1 with mlp_s16.hip's kernel for every narrow job
+static int g_dw_narrow_first = 1;   // "dw_narrow_first": order of the two weight-gradient launches (A/B knob; same gradients either way)
 static int g_dw_job_mask = 0;  // diagnostic: nonzero = run only these dW jobs (bit j)
 static int g_tile_pad16 = 0;     // extra 16-byte units between sample tiles of the fragment stores
 static inline int64_t astride16() { return (int64_t)L::A_SLOTS * 64 + g_tile_pad16; }
@@ -1635,6 +1636,12 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "dw_private_tiles")) { g_dw_private = value < 0 ? 0 : value > 4 ? 4 : value; return NERF_OK; }
   if (!strcmp(key, "dw_ring_cap")) { g_dw_ring_cap = value < 2 ? 2 : value > 16 ? 16 : value; return NERF_OK; }
   if (!strcmp(key, "pass_queue")) { g_pass_queue = value ? 1 : 0; return NERF_OK; }
+  if (!strcmp(key, "dw_narrow_first")) { g_dw_narrow_first = value ? 1 : 0; return NERF_OK; }
+  if (!strcmp(key, "f22_tiles")) {
+    NERF_REQUIRE(value == 2 || value == 3, NERF_E_UNSUPPORTED, "nerf_set_option: f22_tiles must be 2 or 3");
+    f22::g_tiles = value;
+    return NERF_OK;
+  }
   return fail(NERF_E_UNSUPPORTED, "nerf_set_option: unknown key '%s'", key);
 }
 
@@ -1655,6 +1662,8 @@ extern "C" int nerf_get_option(const char* key) {
   if (!strcmp(key, "dw_private_tiles")) return g_dw_private;
   if (!strcmp(key, "dw_ring_cap")) return g_dw_ring_cap;
   if (!strcmp(key, "pass_queue")) return g_pass_queue;
+  if (!strcmp(key, "dw_narrow_first")) return g_dw_narrow_first;
+  if (!strcmp(key, "f22_tiles")) return f22::g_tiles;
   return NERF_OPTION_UNKNOWN;
 }
 
@@ -1989,13 +1998,16 @@ static int launch_dw(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, const v
     else rest.jobs[nrest++] = d.jobs[j];
   }
   const int half = DW_MAX_WGS / 2;
-  if (nwide) {
-    const int rc = launch_dw_part(wide, nwide, ntiles, nparams, acts, dz, astride, zstride, grads, s, split_bf16 ? 2 : 3, a_lo, z_lo, half, half);
-    if (rc) return rc;
-  }
-  if (nrest) {
-    const int rc = launch_dw_part(rest, nrest, ntiles, nparams, acts, dz, astride, zstride, grads, s, split_bf16 ? 1 : 0, a_lo, z_lo, 0, half);
-    if (rc) return rc;
+  for (int turn = 0; turn < 2; ++turn) {        // "dw_narrow_first" 1: the load-bound narrow jobs before the MFMA-bound 256 x 256 jobs
+    const bool do_wide = (turn == 0) != (g_dw_narrow_first != 0);
+    if (do_wide && nwide) {
+      const int rc = launch_dw_part(wide, nwide, ntiles, nparams, acts, dz, astride, zstride, grads, s, split_bf16 ? 2 : 3, a_lo, z_lo, half, half);
+      if (rc) return rc;
+    }
+    if (!do_wide && nrest) {
+      const int rc = launch_dw_part(rest, nrest, ntiles, nparams, acts, dz, astride, zstride, grads, s, split_bf16 ? 1 : 0, a_lo, z_lo, 0, half);
+      if (rc) return rc;
+    }
   }
   return NERF_OK;
 }

@@ -18,6 +18,7 @@ namespace f22 {
 constexpr int F_PAIRS = 1172, F_FRAGS = 2 * F_PAIRS, F_PADDED = 2368, BIAS_FLOATS = 2496;
 constexpr int64_t PACKED_BYTES = (int64_t)F_PADDED * 1024 + (int64_t)BIAS_FLOATS * 4;
 
+extern int g_tiles;    // "f22_tiles" (mlp22.hip)
 int pack(const float* params, void* packed22, hipStream_t s);
 // x != nullptr: embedded rows [M,90]; else rays [B,11] + z [B,n] with the encodings evaluated in the kernel.
 // persistent_wgs: workgroups of the persistent launch (one per CU)

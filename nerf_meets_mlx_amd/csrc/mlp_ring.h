@@ -102,7 +102,9 @@ extern __shared__ __attribute__((aligned(16))) char ring_smem[];
 // 64 KiB lets two independent 4-wave workgroups share a CU, see mlp_fwd_ring_kernel)
 // RUN4 (needs NERF_DMA_CLOBBER_M0 and 8 DMAs per wave and chunk): see issue_one.  Opt-in per kernel (the 4-wave rings of the
 // split-precision kernels).
-template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES, bool RUN4 = false>
+// SPREAD2: a ring with RING_GROUP 2 also spreads its refill DMAs over the chunk interval (off for the training forwards, which were tuned
+// with the burst; on for the 48-sample split-fp16 forward, which has no registers for groups of 4)
+template <int NCHUNK, int TOTAL, int RING_GROUP = 4, int NW = 8, int CHUNK = RING_CHUNK, int STAGES = RING_STAGES, bool RUN4 = false, bool SPREAD2 = false>
 struct RingW {
   static constexpr int DPW = CHUNK / NW;               // DMAs per wave per chunk
   static constexpr int STAGE_BYTES = CHUNK * 1024, BIAS_OFF = STAGES * STAGE_BYTES, LDS_BYTES = BIAS_OFF + 2560 * 4;
@@ -161,7 +163,7 @@ struct RingW {
   // (not in the activation-storing training forward, RING_GROUP 2: it is at the VGPR limit and HBM-bound anyway)
   // RING_GROUP 8 (a group = 8 fragments = a quarter chunk: reads issued twice as far ahead of their use): two refill DMAs per group
   static constexpr int DMA_PER_GROUP = RING_GROUP * DPW / CHUNK;        // 1 (group 4, DPW 8) or 2 (group 8, DPW 8)
-  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && (RING_GROUP == 4 || (RING_GROUP == 8 && DPW == 8)) && (c + 1) * CHUNK <= TOTAL; }
+  static constexpr bool spread(int c) { return NERF_SPREAD_DMA && (RING_GROUP == 4 || (RING_GROUP == 2 && SPREAD2) || (RING_GROUP == 8 && DPW == 8)) && (c + 1) * CHUNK <= TOTAL; }
   __device__ __forceinline__ void boundary(int c, int lane) {
     ring_pos = (ring_pos + 1) & (STAGES - 1);
 #if NERF_ABLATE == 1          // timing-only: no workgroup barrier (results are garbage)
@@ -282,8 +284,8 @@ struct Stamp2 {
 template <class WS> struct is_ring { static constexpr bool value = false; };
 // wave id of a ring source (the pass queue's wave 0); the L1 / LDS-resident sources never run a queue
 template <class WS> __device__ __forceinline__ int ws_wave(const WS&) { return 0; }
-template <int N, int T, int G, int W, int C, int S, bool R> __device__ __forceinline__ int ws_wave(const RingW<N, T, G, W, C, S, R>& w) { return w.wv; }
-template <int N, int T, int G, int W, int C, int S, bool R> struct is_ring<RingW<N, T, G, W, C, S, R>> { static constexpr bool value = true; };
+template <int N, int T, int G, int W, int C, int S, bool R, bool P> __device__ __forceinline__ int ws_wave(const RingW<N, T, G, W, C, S, R, P>& w) { return w.wv; }
+template <int N, int T, int G, int W, int C, int S, bool R, bool P> struct is_ring<RingW<N, T, G, W, C, S, R, P>> { static constexpr bool value = true; };
 
 template <class WS>
 __device__ __forceinline__ bf16x8 next_frag(WS& ws, int f, int lane) { return ws.frag(f, lane); }

@@ -398,3 +398,33 @@ def test_pass_queue_changes_no_result(precision):
             assert torch.equal(m.query(rays, z), first), i
     finally:
         _native.check(lib.nerf_set_option(b"pass_queue", 1))
+
+
+# ------------------------------------------------------------------------------------------------ 48 samples per wave
+def test_split_fp16_forward_with_48_samples_per_wave_is_bit_identical():
+    """"f22_tiles" 3 (the default since round 6: three 16-sample tiles per wave, every weight fragment pair read from the LDS feeds 9
+    MFMAs instead of 6; the 6 floats of a sample parked in the LDS and the encodings re-evaluated where the skip connection and
+    the view layer read them) against 2 (rounds 4-5): the same MFMA sequence per sample -> bit-identical raw outputs, at ragged
+    sizes, for more and for fewer passes than workgroups, with non-finite inputs included."""
+    from nerf_meets_mlx_amd import _native
+    lib = _native.lib()
+    m, arch, p = _view_model(22, seed=6)
+    assert lib.nerf_get_option(b"f22_tiles") == 3
+    try:
+        for B, n in ((1, 1), (3, 16), (37, 45), (1000, 64), (2731, 192), (4096, 64)):
+            gg = torch.Generator().manual_seed(B + n)
+            rays = _rays(B, B + 1)
+            if B > 30:
+                _put(rays, (17, 1), POISON["-nan"]); _put(rays, (23, 9), POISON["+inf"])
+            rays = rays.to(DEV)
+            z = torch.sort(torch.rand(B, n, generator=gg) * 4 + 2, -1).values.to(DEV)
+            got = {}
+            for t in (3, 2):
+                _native.check(lib.nerf_set_option(b"f22_tiles", t))
+                got[t] = m.query(rays, z).clone()
+            a, b = got[3].view(torch.int32), got[2].view(torch.int32)
+            assert torch.equal(torch.isnan(got[3]), torch.isnan(got[2]))
+            ok = torch.isnan(got[3]) | (a == b)
+            assert bool(ok.all()), (B, n, int((~ok).sum()))
+    finally:
+        _native.check(lib.nerf_set_option(b"f22_tiles", 3))
