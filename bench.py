@@ -43,7 +43,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: fp32 matrix (v_
 # fp32: [tile][row][32] float rows)
 TRAIN_BYTES = {16: (321 + 356 + 9) * 1024 / 32, 22: (633 + 712 + 9 + 12) * 1024 / 32, 32: (2592 + 2496) * 128 * 2 / 32}
 PEAK_TFLOPS = {16: BF16_MFMA_PEAK_TFLOPS, 22: BF16_MFMA_PEAK_TFLOPS / 3.0, 32: FP32_MFMA_PEAK_TFLOPS}
-KERNEL = {16: "mlp_fwd_ring16_kernel<8,2>", 22: "mlp22_fwd_kernel<1>", 32: "mlp32_fwd_kernel"}
+KERNEL = {16: "mlp_fwd_ring16_kernel<8,2>", 22: "mlp22_fwd_kernel<1,3>", 32: "mlp32_fwd_kernel"}
 # what the MFMA OPERANDS are (the label says operands, not the tolerance met): precision 22 carries every float32 GEMM operand as
 # two 16-bit numbers -- fp16 x 2 in rendering (22 significand bits), bf16 x 2 in training (16 significand bits) -- and accumulates
 # in fp32; it is held to the float32 kernels' fixture tolerances (1e-4 of the output scale), but its operands are NOT float32

@@ -367,6 +367,14 @@ int nerf_comm_destroy(void* comm);
  *                     consecutive depths of one ray.  Same values per sample either way.
  *   "ring_split"      1 (default): one 8-wave workgroup per CU behind a 128 KiB weight ring; 2: two independent 4-wave
  *                     workgroups behind 64 KiB rings (training forward / chain only; measured slower)
+ *   "pass_queue"      1 (default): the persistent ring kernels (render forwards, training forwards and chains) hand out their passes
+ *                     from a device-wide counter -- a workgroup on a fast XCD takes more passes than one on a slow XCD --; 0: static
+ *                     split (pass = blockIdx.x + k gridDim.x).  Bit-identical results: which workgroup runs a pass changes nothing in it.
+ *   "f22_tiles"       16-sample tiles per wave of the split-fp16 inference forward on rays + depths (precision 22): 3 (default: 48 samples
+ *                     per wave, every weight fragment pair read from the LDS feeds 9 MFMAs) | 2 (rounds 4-5: 32 samples, 6 MFMAs).  The
+ *                     same MFMA sequence per sample: bit-identical results.
+ *   "dw_narrow_first" order of the two weight-gradient launches: 1 (default) the narrow jobs before the 256 x 256 jobs | 0 after.
+ *                     Same gradients either way.
  * nerf_get_option returns the current value of EVERY key nerf_set_option accepts (a get / set pair restores a setting;
  * "dw_unit_bias" reads -1 while it is automatic), or NERF_OPTION_UNKNOWN for an unknown key.                        */
 #define NERF_OPTION_UNKNOWN (-2147483647 - 1)

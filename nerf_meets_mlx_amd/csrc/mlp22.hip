@@ -204,11 +204,17 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
 // Stream fragments 2 (pbase + nt KS + ks) = hi and + 1 = lo of the weight tile.  NS = 2: the shipped form (32 samples per wave);
 // NS = 3: 48 samples per wave -- every weight fragment pair read from the LDS then feeds 9 MFMAs instead of 6 (a third fewer
 // LDS reads, ring DMAs and chunk barriers per sample), at 1.5 x the activation registers.
-template <int NS, int KS, int NT, bool RELU, class WS>
+// PARK_LDS != 0 (pos5 of the 48-sample form, the one layer whose inputs + outputs + accumulators + weight groups exceed the 512
+// registers by one fragment): the LAST input fragment (lo part of k-step KS - 1, sample tile NS - 1) lives in the LDS for the length of
+// the layer -- written once at its head, read back behind the weight fragments of every n-tile (16 ds_read_b128 of 2 400 per pass).
+// Left to hipcc the same fragment goes to scratch, and a scratch reload is a compiler-counted VMEM load: s_waitcnt vmcnt(0), a drain
+// of the weight ring in the middle of a pass.  park_addr: LDS byte address of this lane's 16 bytes.
+template <int NS, int KS, int NT, bool RELU, class WS, bool PARK_LDS = false>
 __device__ __forceinline__ void layer22(WS& ws, int pbase, int bias_slot, const u32x4 (&ih)[NS][KS], const u32x4 (&il)[NS][KS],
-                                        u32x4 (&oh)[NS][NT / 2], u32x4 (&ol)[NS][NT / 2], int lane) {
+                                        u32x4 (&oh)[NS][NT / 2], u32x4 (&ol)[NS][NT / 2], int lane, unsigned park_addr = 0u) {
   const int g = lane >> 4;
   f32x4 pm[NS], pc[NS];
+  if (PARK_LDS) asm volatile("ds_write_b128 %0, %1" :: "v"(park_addr), "v"(il[NS - 1][KS - 1]) : "memory");
 #if NERF_F22_IGLP >= 0
   // LLVM's MFMA-interleaving scheduling strategy for this region (the layer is one basic block): the static gap model goes from 0.770
   // to 0.792 busy (tools/isa_gap_stats.py), measured 15.6-16.1 against 16.1-16.3 ms per fine pass in alternating runs (round 5).
@@ -268,7 +274,16 @@ __device__ __forceinline__ void layer22(WS& ws, int pbase, int bias_slot, const 
         c[1] = mfma16(al, ih[1][ks], c[1]);
       } else {
 #pragma unroll
-        for (int t = 0; t < NS; ++t) { m[t] = mfma16(ah, ih[t][ks], m[t]); c[t] = mfma16(ah, il[t][ks], c[t]); }
+        for (int t = 0; t < NS; ++t) {
+          m[t] = mfma16(ah, ih[t][ks], m[t]);
+          if (PARK_LDS && t == NS - 1 && ks == KS - 1) {
+            u32x4 b;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(park_addr) : "memory");
+            c[t] = mfma16(ah, b, c[t]);
+          } else {
+            c[t] = mfma16(ah, il[t][ks], c[t]);
+          }
+        }
 #pragma unroll
         for (int t = 0; t < NS; ++t) c[t] = mfma16(al, ih[t][ks], c[t]);
       }
@@ -330,7 +345,7 @@ __device__ __forceinline__ void head22(WS& ws, int pbase, int bias_slot, const u
 // 21 spilled VGPRs) every reload is a compiler-counted VMEM load, i.e. an s_waitcnt vmcnt(0) that drains the weight ring.
 constexpr int NW22 = 4, NW22_ = NW22;
 constexpr int PARK_OFF = RING_LDS_BYTES;                                  // behind ring + bias slots
-template <int NS> constexpr int park_bytes() { return NS > 2 ? 6 * NS * 64 * NW22_ * 4 : 0; }
+template <int NS> constexpr int park_bytes() { return NS > 2 ? (6 * NS + 4) * 64 * NW22_ * 4 : 0; }      // + one 16-byte fragment per lane (layer22, PARK_LDS)
 // (the slot offset is an immediate of the instruction: ONE address register for all 18 values)
 template <int K> __device__ __forceinline__ void lds_put(unsigned addr, float v) {
   asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(addr), "v"(v), "i"(1024 * K) : "memory");
@@ -413,7 +428,8 @@ __device__ __forceinline__ void tiles22(const FwdArgs& a, WS& ws, int64_t wtile0
 #pragma unroll
       for (int k = 0; k < 8; ++k) { cth[s][2 + k] = hah[s][k]; ctl[s][2 + k] = hal[s][k]; }
     }
-    layer22<NS, 10, 16, true>(ws, L16::F_L5, 1280, cth, ctl, hbh, hbl, lane);
+    layer22<NS, 10, 16, true, WS, (NS > 2)>(ws, L16::F_L5, 1280, cth, ctl, hbh, hbl, lane,
+                                            ws.lds0 + PARK_OFF + 6 * NS * 64 * NW22 * 4 + 16u * (unsigned)(ws.wv * 64 + lane));
   }
   layer22<NS, 8, 16, true>(ws, L16::F_L6, 1536, hbh, hbl, hah, hal, lane);
   layer22<NS, 8, 16, true>(ws, L16::F_L7, 1792, hah, hal, hbh, hbl, lane);

@@ -33,7 +33,8 @@ DYNAMIC_LDS = {
     "mlp_small_fwd_kernel": 32 * 1024 + 288 * 4,              # LN::LDS_BYTES: resident fragment stream + biases
     "mlp_small_bwd_kernel": 32 * 1024 + 288 * 4,
     "mlp32_fwd_kernel": 4 * 256 * 32 * 4, "mlp32_bwd_kernel": 4 * 256 * 32 * 4,     # one 32 KiB slab per wave
-    "mlp22_fwd_kernel": 4 * 32 * 1024 + 2560 * 4,             # split-fp16 render forward: the same ring
+    "mlp22_fwd_kernel<1, 3>": 160 * 1024,                     # split-fp16 render forward, 48 samples per wave: ring + bias slots + 22 KiB of parked sample floats / one fragment
+    "mlp22_fwd_kernel": 4 * 32 * 1024 + 2560 * 4,             # ... 32 samples per wave / embedded rows: the ring + bias slots
     "s16_fwd_kernel": 4 * 32 * 1024 + 2560 * 4, "s16_bwd_kernel": 4 * 32 * 1024 + 2560 * 4,   # split-bf16 training: the same ring
     "mlp_dww_kernel": 4 * 32 * 1024,                          # 256 x 256 jobs: 4 stages x 32 pair blocks of 1 KiB
     "s16_dw_kernel": 160 * 1024,                              # the other jobs: a ring over the whole LDS of the CU
