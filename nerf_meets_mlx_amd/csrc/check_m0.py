@@ -28,8 +28,13 @@ def main():
         if a.kernels and not any(k in name for k in a.kernels):
             continue
         end = text.find(".Lfunc_end", m.end())
+        nxt = re.search(r"^_Z[^\n:]*:", text[m.end():], re.M)
+        if end < 0 or (nxt and m.end() + nxt.start() < end):
+            continue                                   # a data symbol (a __device__ variable): no function end before the next symbol
         body = [ln.split(";")[0].strip() for ln in text[m.end():end].split("\n")]
         body = [ln for ln in body if ln and not ln.startswith(".")]
+        if not body:
+            continue                                   # a data symbol (a __device__ variable), not a function
         seen += 1
         ours = other = 0
         for i, ln in enumerate(body):

@@ -98,7 +98,11 @@ def test_shipped_split_kernels_passed_the_build_time_scans():
         pytest.skip("no in-tree build directory (library built elsewhere)")
     # (object, kernels scanned, of which ring kernels that issue LDS-DMA): mlp_s16x's 2 x 64 kernels keep their weights LDS-resident
     # every kernel of a unit is scanned (round 5): pack kernels and the weight-gradient kernels included
-    for name, kernels, ring in (("mlp22_m0_scan.txt", 3, 2), ("mlp_s16_m0_scan.txt", 6, 5), ("mlp_dww_m0_scan.txt", 2, 2),
+    # round 6: mlp22.o holds a fourth kernel, the 48-samples-per-wave forward, which sits at the edge of the 512-register file: up to 6
+    # scratch instructions are accepted THERE (thread id kept for the end of the kernel, two address temporaries at the head of a pass --
+    # none between the head and the end of a pass, where a scratch reload would drain the weight ring), nowhere else
+    edge = {"mlp22_fwd_kernelILi1ELi3E": 6}
+    for name, kernels, ring in (("mlp22_m0_scan.txt", 4, 3), ("mlp_s16_m0_scan.txt", 6, 5), ("mlp_dww_m0_scan.txt", 2, 2),
                                 ("mlp_s16x_m0_scan.txt", 10, 3)):
         path = os.path.join(build, name)
         assert os.path.exists(path), f"{name} missing: the Makefile rule of the split kernels did not run"
@@ -107,7 +111,8 @@ def test_shipped_split_kernels_passed_the_build_time_scans():
         with_dma = 0
         for ln in rows:
             m = re.search(r": (\d+) LDS-DMA M0 writes, (\d+) other M0 uses, (\d+) scratch instructions", ln)
-            assert m and int(m.group(2)) == 0 and int(m.group(3)) == 0, ln
+            allowed = max([n for k, n in edge.items() if k in ln] or [0])
+            assert m and int(m.group(2)) == 0 and int(m.group(3)) <= allowed, ln
             with_dma += int(m.group(1)) > 0
         assert with_dma == ring, rows
     scan32 = os.path.join(build, "mlp32_inflight_scan.txt")
