@@ -16,7 +16,7 @@ list is reported.  Kernels whose loads are all compiler-managed never trip it in
 false positives there (pass --kernels to restrict the scan to the asm-load kernels).
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -S --cuda-device-only -o /tmp/mlp32.s nerf_meets_mlx_amd/csrc/mlp32.hip
-    python tools/check_inflight_regs.py /tmp/mlp32.s --kernels mlp32_fwd_kernel mlp32_bwd_kernel mlp32_dw_kernel
+    python nerf_meets_mlx_amd/csrc/check_inflight_regs.py /tmp/mlp32.s --kernels mlp32_fwd_kernel mlp32_bwd_kernel mlp32_dw_kernel
 """
 import argparse
 import re

@@ -4,7 +4,7 @@
     python tools/bench_kernels.py > profiles/r01_hbm_kernels.csv
 
 Algorithmic bytes = compulsory reads + writes of the call's tensors (each counted once); peak 8 TB/s HBM3E
-(MI355X_MICROARCH.md); the streaming ceilings measured with tools/hbm_probe.hip on this pool are 5.4-5.8 (stores) and
+(MI355X_MICROARCH.md); the streaming ceilings measured with tools/attic/hbm_probe.hip on this pool are 5.4-5.8 (stores) and
 6.2-7.1 TB/s (loads).  Timing: HIP events around 20 back-to-back launches on the launch stream."""
 import sys, torch
 sys.path.insert(0, ".")
