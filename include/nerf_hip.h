@@ -370,9 +370,11 @@ int nerf_comm_destroy(void* comm);
  *   "pass_queue"      1 (default): the persistent ring kernels (render forwards, training forwards and chains) hand out their passes
  *                     from a device-wide counter -- a workgroup on a fast XCD takes more passes than one on a slow XCD --; 0: static
  *                     split (pass = blockIdx.x + k gridDim.x).  Bit-identical results: which workgroup runs a pass changes nothing in it.
- *   "f22_tiles"       16-sample tiles per wave of the split-fp16 inference forward on rays + depths (precision 22): 3 (default: 48 samples
- *                     per wave, every weight fragment pair read from the LDS feeds 9 MFMAs) | 2 (rounds 4-5: 32 samples, 6 MFMAs).  The
+ *   "f22_tiles"       16-sample tiles per wave of the split-fp16 inference forward on rays + depths (precision 22): 3 (48 samples per
+ *                     wave, every weight fragment pair read from the LDS feeds 9 MFMAs) | 2 (rounds 4-5: 32 samples, 6 MFMAs) | 0 (default)
+ *                     = 3 except for launches of a few passes per workgroup where whole 32-sample passes divide the work better.  The
  *                     same MFMA sequence per sample: bit-identical results.
+ *   "dw_unit_bias"    (see above) automatic = 128 for the bf16 kernels, 2 for the split-bf16 kernels (round 6: was 32)
  *   "dw_narrow_first" order of the two weight-gradient launches: 1 (default) the narrow jobs before the 256 x 256 jobs | 0 after.
  *                     Same gradients either way.
  * nerf_get_option returns the current value of EVERY key nerf_set_option accepts (a get / set pair restores a setting;

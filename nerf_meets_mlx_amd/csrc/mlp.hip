@@ -1638,7 +1638,7 @@ extern "C" int nerf_set_option(const char* key, int value) {
   if (!strcmp(key, "pass_queue")) { g_pass_queue = value ? 1 : 0; return NERF_OK; }
   if (!strcmp(key, "dw_narrow_first")) { g_dw_narrow_first = value ? 1 : 0; return NERF_OK; }
   if (!strcmp(key, "f22_tiles")) {
-    NERF_REQUIRE(value == 2 || value == 3, NERF_E_UNSUPPORTED, "nerf_set_option: f22_tiles must be 2 or 3");
+    NERF_REQUIRE(value == 0 || value == 2 || value == 3, NERF_E_UNSUPPORTED, "nerf_set_option: f22_tiles must be 0 (automatic), 2 or 3");
     f22::g_tiles = value;
     return NERF_OK;
   }
@@ -1913,9 +1913,13 @@ static int launch_dw_part(DwArgs& d, int nj, int64_t ntiles, int64_t nparams, co
   // A job's cost per sample tile = its bytes (nf + kf KiB) + a fixed part (barrier, waits, the 4 DMA issues per wave,
   // transposed reads, MFMAs) worth about 128 KiB of streaming: single-job timings fit t = a (nf + kf + c0) with c0 = 24
   // at a full grid, but under load the sweep over c0 keeps improving up to ~128 and is flat beyond (tools/sweep_dw.py).  Split the sample range of every job in proportion.
+  // Split-bf16 kernels (round 6): since the 256 x 256 jobs run in a launch of their own (all equal: the bias is moot there), the bias only
+  // balances the six narrow jobs among themselves, and their times alone fit t = 9.0 (nf + kf) + 0 ... 14: 32 gave the two tiny jobs
+  // (dir0 | dirPE, rgb) 36 workgroups each instead of 26-28 and the launch waited for dir0 | feature; 2 is worth -1.8 % of the
+  // training step (tools/ab_train_step.py dw_unit_bias -1 2: 10.66 -> 10.46 ms; 0 / 1 / 3 within noise of it, 8: -0.8 %).
   int64_t units[DW_MAX_JOBS], total_units = 0;
   for (int j = 0; j < nj; ++j) {
-    units[j] = d.jobs[j].nf + d.jobs[j].kf + (g_dw_bias >= 0 ? g_dw_bias : split_bf16 ? 32 : 128);
+    units[j] = d.jobs[j].nf + d.jobs[j].kf + (g_dw_bias >= 0 ? g_dw_bias : split_bf16 ? 2 : 128);
     total_units += units[j];
   }
   // One workgroup per CU and launch (256), shares by largest remainder so that they sum to exactly 256: every

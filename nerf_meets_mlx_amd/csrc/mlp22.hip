@@ -505,7 +505,10 @@ int pack(const float* params, void* packed22, hipStream_t s) {
   return check_launch("nerf_mlp_pack (split-fp16 image)");
 }
 
-int g_tiles = 3;       // nerf_set_option("f22_tiles"): 16-sample tiles per wave of the rays + depths launch: 2 (32 samples) | 3 (48 samples)
+// nerf_set_option("f22_tiles"): 16-sample tiles per wave of the rays + depths launch: 2 (32 samples) | 3 (48 samples) | 0 (default) = 3
+// unless the launch is so small that whole passes per workgroup decide: a 48-sample pass takes 1.41 x a 32-sample pass (113 against 80
+// us), so 4096 x 64 samples (the training step's re-query of the coarse network) are 8 x 1 against 6 x 1.41 pass times per workgroup
+int g_tiles = 0;
 
 int forward(const void* packed22, const float* x, const float* rays, const float* z, int64_t M, int n, int freq_mode,
             float* out, int persistent_wgs, hipStream_t s) {
@@ -517,7 +520,13 @@ int forward(const void* packed22, const float* x, const float* rays, const float
   a.x = x; a.rays = rays; a.z = z; a.M = M; a.n = n; a.out = out; a.acts = nullptr; a.astride = 0;
   for (int k = 0; k < 10; ++k) a.fr.pos[k] = freq_mode == 0 ? (float)(k * k) : (float)(1 << k);
   for (int k = 0; k < 4; ++k) a.fr.dir[k] = freq_mode == 0 ? (float)(k * k) : (float)(1 << k);
-  const int mode = x ? 0 : (g_tiles == 3 ? 2 : 1);
+  int tiles = g_tiles;
+  if (tiles == 0) {
+    const int64_t w = persistent_wgs > 0 ? persistent_wgs : 1;
+    const int64_t p2 = (((M + 31) / 32 + NW22 - 1) / NW22 + w - 1) / w, p3 = (((M + 47) / 48 + NW22 - 1) / NW22 + w - 1) / w;     // passes of the busiest workgroup
+    tiles = 100 * p2 < 141 * p3 ? 2 : 3;
+  }
+  const int mode = x ? 0 : (tiles == 3 ? 2 : 1);
   const int ns = mode == 2 ? 3 : 2;
   const int64_t nsuper = ((M + 16 * ns - 1) / (16 * ns) + NW22 - 1) / NW22;
   const dim3 g((unsigned)(nsuper < persistent_wgs ? nsuper : persistent_wgs)), b(64 * NW22);

@@ -409,7 +409,7 @@ def test_split_fp16_forward_with_48_samples_per_wave_is_bit_identical():
     from nerf_meets_mlx_amd import _native
     lib = _native.lib()
     m, arch, p = _view_model(22, seed=6)
-    assert lib.nerf_get_option(b"f22_tiles") == 3
+    assert lib.nerf_get_option(b"f22_tiles") == 0          # automatic: 3 except for launches of a few passes per workgroup
     try:
         for B, n in ((1, 1), (3, 16), (37, 45), (1000, 64), (2731, 192), (4096, 64)):
             gg = torch.Generator().manual_seed(B + n)
@@ -427,4 +427,4 @@ def test_split_fp16_forward_with_48_samples_per_wave_is_bit_identical():
             ok = torch.isnan(got[3]) | (a == b)
             assert bool(ok.all()), (B, n, int((~ok).sum()))
     finally:
-        _native.check(lib.nerf_set_option(b"f22_tiles", 3))
+        _native.check(lib.nerf_set_option(b"f22_tiles", 0))

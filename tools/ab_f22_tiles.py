@@ -35,4 +35,4 @@ for r in range(4):
             res[t][n].append(e0.elapsed_time(e1) / 10)
 for t in (2, 3):
     print(f"f22_tiles {t}: coarse " + " ".join(f"{x:.3f}" for x in res[t][64]) + " ms | fine " + " ".join(f"{x:.3f}" for x in res[t][192]) + " ms")
-_native.check(lib.nerf_set_option(b"f22_tiles", 2))
+_native.check(lib.nerf_set_option(b"f22_tiles", 0))
