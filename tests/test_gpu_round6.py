@@ -428,3 +428,33 @@ def test_split_fp16_forward_with_48_samples_per_wave_is_bit_identical():
             assert bool(ok.all()), (B, n, int((~ok).sum()))
     finally:
         _native.check(lib.nerf_set_option(b"f22_tiles", 0))
+
+
+@pytest.mark.parametrize("precision", [22, 16])
+def test_non_finite_rays_through_the_fused_hash_grid_query(precision):
+    """configs[4]: a NaN / Inf ray through `HashNeRF.query` (hash gathers + interpolation + SH + the 2 x 64 network in one kernel,
+    ray-major inference tiles and sample-major training tiles): a poisoned position (table indices stay inside the tables: every
+    corner index is hashed and masked, `encoding/multi_hash.py:112-131`) makes all four outputs of that ray's samples NaN, a poisoned
+    view direction its colours; every other ray is bit-identical to the clean run, fused and unfused paths agree on the pattern."""
+    from nerf_meets_mlx_amd.engine.ngp import HashNeRF
+    f = HashNeRF(device=DEV, seed=3, log2_hashmap_size=14, precision=precision)
+    f.enc.tables.normal_(0.0, 0.3)
+    if f.table.half is not None:
+        f.table.mark_updated()
+    B, n, bad = 70, 64, 33
+    rays = _rays(B, 4)
+    z = torch.linspace(2.0, 6.0, n).expand(B, n).contiguous().to(DEV)
+    for train in (False, True):
+        clean = f.query(rays.to(DEV), z, train=train).clone()
+        assert torch.isfinite(clean).all()
+        keep = torch.arange(B) != bad
+        for name, u in POISON.items():
+            for col, all_four in ((0, True), (5, True), (10, False)):
+                r2 = rays.clone()
+                _put(r2, (bad, col), u)
+                for fused in (True, False):
+                    raw = f.query(r2.to(DEV), z, train=train, fused=fused).cpu()
+                    nan = torch.isnan(raw[bad])
+                    assert bool(nan[:, :3].all()) and bool(nan[:, 3].all()) == all_four, (precision, train, name, col, fused)
+                    if fused:
+                        assert torch.equal(raw[keep], clean.cpu()[keep]), (precision, train, name, col)
