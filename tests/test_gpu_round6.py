@@ -458,3 +458,33 @@ def test_non_finite_rays_through_the_fused_hash_grid_query(precision):
                     assert bool(nan[:, :3].all()) and bool(nan[:, 3].all()) == all_four, (precision, train, name, col, fused)
                     if fused:
                         assert torch.equal(raw[keep], clean.cpu()[keep]), (precision, train, name, col)
+
+
+def test_pass_queue_under_concurrent_streams():
+    """Launches of the persistent kernels in flight at the same time on different streams take different queue slots (round-robin per
+    translation unit): two streams interleaving render forwards, training forwards and backward chains of two models give, launch for
+    launch, what the same calls give one after the other on one stream."""
+    m1, _, _ = _view_model(22, seed=8)
+    m2, _, _ = _view_model(22, seed=9)
+    rays = _rays(900, 12).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    z = torch.sort(torch.rand(900, 64, generator=g) * 4 + 2, -1).values.to(DEV)
+    d_raw = torch.randn(900, 64, 4, generator=g).to(DEV)
+    want = []
+    for m in (m1, m2):
+        inf = m.query(rays, z).clone()
+        trn = m.query(rays, z, train=True).clone()
+        want.append((inf, trn, m.backward(d_raw).clone()))
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    got = {0: [], 1: []}
+    for rep in range(20):
+        for i, (m, s) in enumerate(((m1, s1), (m2, s2))):
+            with torch.cuda.stream(s):
+                inf = m.query(rays, z)
+                trn = m.query(rays, z, train=True)
+                got[i].append((inf, trn, m.backward(d_raw).clone()))
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        for inf, trn, gr in got[i]:
+            assert torch.equal(inf, want[i][0]) and torch.equal(trn, want[i][1]) and torch.equal(gr, want[i][2])
