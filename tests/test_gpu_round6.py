@@ -331,16 +331,16 @@ def test_importance_sampler_index_mismatches_at_render_chunk_size():
 
 
 # ------------------------------------------------------------------------------------------------ the --gpus N line explains itself
-@pytest.mark.parametrize("extra", [[], ["--config", "ngp"]])
-def test_bench_two_rank_line_carries_the_communicator(extra):
-    """`bench.py --gpus 2` (self-spawned ranks; rehearsal transport gloo, both ranks on cuda:0 because RCCL refuses two ranks on
-    one device): the JSON line says which backend the ranks used, how many ranks ANSWERED an all-reduce before the timed region
+@pytest.mark.parametrize("extra,world", [([], 2), (["--config", "ngp"], 2), ([], 4)])
+def test_bench_two_rank_line_carries_the_communicator(extra, world):
+    """`bench.py --gpus N`, N = 2 and 4 (self-spawned ranks; rehearsal transport gloo, all ranks on cuda:0 because RCCL refuses two ranks
+    on one device; 4 ranks + this process stay under the box's limit of 6 GPU processes): the JSON line says which backend the ranks used, how many ranks ANSWERED an all-reduce before the timed region
     (`world_size_seen`, asserted == --gpus inside bench.py), every rank's device, and the bytes the data path all-reduces per
     step; value counts both ranks' rays."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NERF_DIST_BACKEND="gloo", NERF_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-rand", "256",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-rand", "256",
            "--render-rays", "2048", "--hw", "64", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -348,14 +348,14 @@ def test_bench_two_rank_line_carries_the_communicator(extra):
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     c = d["comm"]
-    assert d["n_gpus"] == 2 and c["backend"] == "gloo" and c["world_size"] == 2 and c["world_size_seen"] == 2
-    assert [x["rank"] for x in c["devices"]] == [0, 1] and all(x["device"].startswith("cuda") for x in c["devices"])
+    assert d["n_gpus"] == world and c["backend"] == "gloo" and c["world_size"] == world and c["world_size_seen"] == world
+    assert [x["rank"] for x in c["devices"]] == list(range(world)) and all(x["device"].startswith("cuda") for x in c["devices"])
     assert c["allreduce_bytes_per_step"] > 0
     if not extra:
         assert c["allreduce_bytes_per_step"] == 2 * 595844 * 4 and c["collectives_per_step"] == 2
         assert d["comm_ms_per_step"] is not None and d["comm_ms_per_step"] >= 0
-    assert len(d["rank_ms_per_step"]["ranks"]) == 2
-    assert abs(d["value"] - 2 * (256 + 2048) * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert len(d["rank_ms_per_step"]["ranks"]) == world
+    assert abs(d["value"] - world * (256 + 2048) * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
 # ------------------------------------------------------------------------------------------------ dynamic pass queue
