@@ -391,6 +391,16 @@ def test_pass_queue_changes_no_result(precision):
         for a, b in zip(res[0], res[1]):
             assert torch.equal(a, b)
         _native.check(lib.nerf_set_option(b"pass_queue", 1))
+        # other numbers of persistent workgroups than one per CU (fewer: long queues per workgroup; more: most take a single pass)
+        for wgs in (7, 300):
+            _native.check(lib.nerf_set_option(b"ring_workgroups", wgs))
+            rays = _rays(3000, 3000).to(DEV)
+            gg = torch.Generator().manual_seed(3000)
+            z = torch.sort(torch.rand(3000, 192, generator=gg) * 4 + 2, -1).values.to(DEV)
+            d_raw = torch.randn(3000, 192, 4, generator=gg).to(DEV)
+            assert torch.equal(m.query(rays, z), res[1][9]) and torch.equal(m.query(rays, z, train=True), res[1][10])
+            assert torch.equal(m.backward(d_raw), res[1][11]) or precision == 16      # (bf16 dW: the split count follows the workgroup option)
+        _native.check(lib.nerf_set_option(b"ring_workgroups", 0))
         rays = _rays(300, 1).to(DEV)
         z = torch.linspace(2.0, 6.0, 64, device=DEV).expand(300, 64).contiguous()
         first = m.query(rays, z).clone()
@@ -398,6 +408,7 @@ def test_pass_queue_changes_no_result(precision):
             assert torch.equal(m.query(rays, z), first), i
     finally:
         _native.check(lib.nerf_set_option(b"pass_queue", 1))
+        _native.check(lib.nerf_set_option(b"ring_workgroups", 0))
 
 
 # ------------------------------------------------------------------------------------------------ 48 samples per wave

@@ -316,3 +316,22 @@ def test_run_log_jsonl_format(tmp_path):
     assert set(recs[1]) == {"kind", "it", "loss_coarse", "loss_fine", "psnr_coarse", "psnr_fine", "lr", "rays_per_s", "elapsed_s"}
     assert recs[2] == {"kind": "eval", "it": 100, "psnr": 23.5, "view": 7, "seconds": 5.0}
     assert recs[0]["world_size"] == 2 and recs[4]["resumed_from"] == "000200.npz"
+
+
+def test_every_documented_option_is_gettable_and_settable():
+    """include/nerf_hip.h lists the keys of nerf_set_option; nerf_get_option must know every one of them (advisor, round 5: three keys
+    read as -1, the same value as 'unknown' and as the legitimate 'automatic' of dw_unit_bias) and a get / set pair must restore a
+    setting; unknown keys read NERF_OPTION_UNKNOWN (INT_MIN) and are refused by set."""
+    from nerf_meets_mlx_amd import _native
+    lib = _native.lib()
+    text = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    block = text[text.index("runtime selection of kernel variants"):text.index("int nerf_set_option")]
+    keys = sorted(set(re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M)))
+    assert len(keys) >= 14 and {"pass_queue", "f22_tiles", "dw_narrow_first", "dw_unit_bias", "dw_private_tiles", "dw_ring_cap"} <= set(keys), keys
+    for k in keys + ["tile_pad16", "bwd_stage", "dw_job_mask"]:                  # + the undocumented diagnostic knobs
+        v = lib.nerf_get_option(k.encode())
+        assert v != -2 ** 31, f"nerf_get_option does not know '{k}'"
+        assert lib.nerf_set_option(k.encode(), v) == 0, k                      # writing back what was read changes nothing ...
+        assert lib.nerf_get_option(k.encode()) == v, k                          # ... (dw_unit_bias: -1 = automatic stays -1)
+    assert lib.nerf_get_option(b"no_such_key") == -2 ** 31 and lib.nerf_set_option(b"no_such_key", 1) == -3
+    assert lib.nerf_get_option(b"pass_queue") == 1 and lib.nerf_get_option(b"f22_tiles") == 0 and lib.nerf_get_option(b"dw_unit_bias") == -1
