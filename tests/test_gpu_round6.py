@@ -422,7 +422,7 @@ def test_split_fp16_forward_with_48_samples_per_wave_is_bit_identical():
     m, arch, p = _view_model(22, seed=6)
     assert lib.nerf_get_option(b"f22_tiles") == 0          # automatic: 3 except for launches of a few passes per workgroup
     try:
-        for B, n in ((1, 1), (3, 16), (37, 45), (1000, 64), (2731, 192), (4096, 64)):
+        for B, n in ((1, 1), (3, 16), (37, 45), (1000, 64), (2731, 192), (4096, 64), (32768, 192)):      # ... the last: one render chunk's fine pass
             gg = torch.Generator().manual_seed(B + n)
             rays = _rays(B, B + 1)
             if B > 30:
